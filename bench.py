@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- scored phylo-k-mers/s of the hot path on N MI355X (one process per GPU).
+
+A step = one pass of the hot path (prefix array + DCLA scoring + per-branch max-reduce + compaction
+to the sorted per-branch (key, score) sets) over the whole synthetic workload of this rank, with
+the matrices already resident in HBM.  Default workload: BASELINE.json configs[1]
+("Synthetic DNA: 2000 extended nodes x 10000 sites, k=10, omega=1.5, 1xMI355X").
+Branch groups shard across ranks with no data-path collective -> weak scaling (every rank scores
+its own 1000 groups).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--groups", type=int, default=0, help="override the number of branch groups (0 = config's)")
+    ap.add_argument("--alpha", type=float, default=0.0, help="override the column concentration")
+    ap.add_argument("--cpu-groups", type=int, default=-1, help="groups timed on the CPU oracle (-1 = auto, 0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ipk_amd
+    from ipk_amd import engine as E
+    from ipk_amd.synth import CONFIGS, synth_matrices
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = dict(CONFIGS[args.config])
+    if args.groups:
+        cfg["n_groups"] = args.groups
+    if args.alpha:
+        cfg["alpha"] = args.alpha
+    ng, mpg, sites, sigma, k = cfg["n_groups"], cfg["mats_per_group"], cfg["sites"], cfg["sigma"], cfg["k"]
+    n_mats = ng * mpg
+    eps = ipk_amd.log_threshold(cfg["omega"], sigma, k)
+
+    # synthetic matrices of this rank (weak scaling: rank r owns matrices [r*n_mats, (r+1)*n_mats))
+    t0 = time.time()
+    d_logp = torch.empty((n_mats, sites, sigma), dtype=torch.float32, device="cuda")
+    step_m = max(1, min(n_mats, (64 << 20) // (sites * sigma * 4)))
+    for m0 in range(0, n_mats, step_m):
+        m1 = min(n_mats, m0 + step_m)
+        d_logp[m0:m1].copy_(torch.from_numpy(synth_matrices(m1 - m0, sites, sigma, cfg["alpha"], cfg["seed"],
+                                                            first_mat=rank * n_mats + m0)))
+    groups = np.repeat(np.arange(ng, dtype=np.uint32), mpg)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+
+    eng = ipk_amd.Engine(local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    emitted = entries = 0
+    for _ in range(args.warmup):
+        r = eng.score_groups(d_logp, groups, k, eps)
+        emitted, entries = r.emitted, r.num_entries
+        r.free()
+    barrier()
+    t_start = time.perf_counter()
+    score_ms = launches = total_ms = compact_ms = prefix_ms = 0.0
+    for _ in range(args.steps):
+        r = eng.score_groups(d_logp, groups, k, eps)      # returns after the device work completed
+        emitted, entries = r.emitted, r.num_entries
+        score_ms += r.time_ms(E.T_SCORE); launches += r.time_ms(E.T_SCORE_LAUNCHES)
+        total_ms += r.time_ms(E.T_TOTAL); compact_ms += r.time_ms(E.T_COMPACT); prefix_ms += r.time_ms(E.T_PREFIX)
+        r.free()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        e = torch.tensor([emitted], dtype=torch.int64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        emitted_all = int(e.item())
+    else:
+        emitted_all = emitted
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = emitted_all * args.steps / elapsed
+        # roofline of the dominant kernel (scoring + max-reduce): algorithmic bytes per launch =
+        # every matrix read once + one (u32 key, f32 score) pair per scored phylo-k-mer
+        b_alg = n_mats * sites * sigma * 4 + 8 * emitted
+        avg_score_ms = score_ms / max(launches, 1)
+        achieved = b_alg / (avg_score_ms * 1e-3) / 1e9 if avg_score_ms > 0 else 0.0
+        out = {
+            "metric": "scored phylo-k-mers/sec", "value": value, "unit": "phylo-k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: synthetic {'DNA' if sigma == 4 else 'AA'} {n_mats} extended nodes "
+                                   f"({ng} branch groups x {mpg}) x {sites} sites, k={k}, omega={cfg['omega']}, "
+                                   f"alpha={cfg['alpha']}, per GPU",
+                       "scored_per_step_per_gpu": emitted, "branch_kmer_entries_per_gpu": entries,
+                       "sharding": f"branch groups over {world} rank(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "score_tiles_kernel (+ score_overflow_kernel)", "avg_launch_ms": avg_score_ms,
+                         "algorithmic_bytes_per_launch": b_alg},
+            "phases_ms_per_step": {"prefix": prefix_ms / args.steps, "score": score_ms / args.steps,
+                                   "compact": compact_ms / args.steps, "device_total": total_ms / args.steps},
+            "setup_s": {"synth_and_upload": t_gen},
+        }
+        # CPU baseline: the oracle (C restatement), 1 thread, bounded sample of the same workload
+        n_cpu = args.cpu_groups
+        if world == 1 and n_cpu != 0:
+            from oracle import ipk_oracle as co
+            if n_cpu < 0:
+                n_cpu = 1
+            probe = synth_matrices(mpg, sites, sigma, cfg["alpha"], cfg["seed"], first_mat=0)
+            tp = time.perf_counter(); co.explore_many(probe, mpg, k, eps); tp = time.perf_counter() - tp
+            if args.cpu_groups < 0:
+                n_cpu = int(max(2, min(ng, 15.0 / max(tp, 1e-3))))
+            sample = synth_matrices(n_cpu * mpg, sites, sigma, cfg["alpha"], cfg["seed"], first_mat=0)
+            tc = time.perf_counter(); e_cpu, _ = co.explore_many(sample, mpg, k, eps); tc = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": e_cpu / tc, "unit": "phylo-k-mers/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {n_cpu} of {ng} branch groups of the same workload "
+                                             f"({e_cpu} scored k-mers, {tc:.1f} s), oracle/ipk_oracle.c -O3, 1 thread "
+                                             f"(the reference build loop is single-threaded)"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/*
+ * ipkgpu.h -- C ABI of the MI355X phylo-k-mer scoring engine (libipkgpu.so).
+ *
+ * Drop-in boundary for ONE path of phylo42/IPK: what db_builder::explore_kmers /
+ * explore_group consume from the scoring layer (citations relative to the IPK tree):
+ *
+ *   ipk/src/db_builder.cpp:576-627   explore_kmers   (the group loop)
+ *   ipk/src/db_builder.cpp:629-698   explore_group   (windows -> DCLA -> put -> DB insert)
+ *   ipk/src/pk_compute.cpp:28-119    DCLA::run / DC  (divide-and-conquer with look-ahead)
+ *   ipk/src/window.cpp:16-27,69-72   matrix::preprocess / range_max_sum
+ *   ipk/src/branch_group.cpp:88-107  put / kmer_batch
+ *
+ * IPK itself has no FFI; INTEGRATION.md shows the ~30-line patch to db_builder.cpp that
+ * binds these entry points.  Plain pointers and sizes only; no exceptions cross the ABI:
+ * every call returns an int status (0 = ok) and ipkgpu_last_error() gives the message.
+ *
+ * Threading: one host thread per context; calls on a context are serialised by the caller.
+ * One context drives one GPU (one process per GPU; multi-GPU sharding is by branch group).
+ */
+#ifndef IPKGPU_H
+#define IPKGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ipkgpu_ctx ipkgpu_ctx;
+typedef struct ipkgpu_result ipkgpu_result;
+
+enum {
+    IPKGPU_OK = 0,
+    IPKGPU_ERR_INVALID = 1,     /* bad argument (sigma/k unsupported, sites < k, null pointer ...) */
+    IPKGPU_ERR_HIP = 2,         /* a HIP runtime call failed */
+    IPKGPU_ERR_NOMEM = 3,       /* device or host allocation failed */
+    IPKGPU_ERR_NODEVICE = 4     /* no usable GPU: the engine has NO CPU fallback */
+};
+
+/* ipkgpu_result_time_ms selectors */
+enum {
+    IPKGPU_T_TOTAL = 0,         /* whole call on the device stream (first event -> last event) */
+    IPKGPU_T_PREFIX = 1,        /* prefix-of-column-maxima kernel  (matrix::preprocess) */
+    IPKGPU_T_SCORE = 2,         /* scoring + max-reduce kernels (DCLA + put), summed over batches */
+    IPKGPU_T_COMPACT = 3,       /* table -> sorted (key, score) compaction kernels */
+    IPKGPU_T_SCORE_LAUNCHES = 4 /* number of scoring-kernel launches the IPKGPU_T_SCORE sum covers */
+};
+
+/* ---- context ------------------------------------------------------------------------- */
+
+/* Creates an engine on HIP device `device_id`.  Fails with IPKGPU_ERR_NODEVICE when no GPU
+ * is present.  (Replaces nothing in IPK; owns the stream and workspaces.) */
+int ipkgpu_create(int device_id, ipkgpu_ctx** ctx);
+void ipkgpu_destroy(ipkgpu_ctx* ctx);
+
+/* Message of the last failing call on this context ("" if none); owned by the context.
+ * ipkgpu_last_error(NULL) returns the message of the last failed ipkgpu_create. */
+const char* ipkgpu_last_error(const ipkgpu_ctx* ctx);
+
+/* Options: "workspace_bytes" (max bytes of per-group score tables resident at once; groups are
+ * processed in batches that fit), "list_cap" (half-list capacity of the fast path; 0 = auto),
+ * "variant" (scoring kernel variant, 0 = auto).  Returns IPKGPU_ERR_INVALID for unknown names. */
+int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value);
+
+/* ---- host helpers (no GPU needed) ------------------------------------------------------ */
+
+/* log10 of IPK's score threshold: db_builder.cpp:640 `std::log10(score_threshold(omega, k))`.
+ * score_threshold is un-vendored i2l code; documented as (omega/sigma)^k
+ * (docs/source/usage.rst:224-229) and evaluated here in float: log10f(powf(omega/sigma, k)). */
+float ipkgpu_log_threshold(float omega, uint32_t sigma, uint32_t k);
+
+/* Bits per symbol of the packed k-mer code: i2l::bit_length<seq_type>() as used at
+ * pk_compute.cpp:99 (sigma 4 -> 2, sigma 20 -> 5).  0 for unsupported sigma. */
+uint32_t ipkgpu_bits_per_symbol(uint32_t sigma);
+
+/* ipk::kmer_batch -- branch_group.cpp:104-107. */
+size_t ipkgpu_kmer_batch(uint32_t key, size_t n_ranges);
+
+/* Largest supported k for an alphabet (DNA: 12, AA: 6); 0 for unsupported sigma. */
+uint32_t ipkgpu_max_k(uint32_t sigma);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/*
+ * Replaces the body of the group loop, db_builder.cpp:606-625 + explore_group :629-698
+ * (RAM mode), for a batch of ghost-node matrices.
+ *
+ *   logp       n_mats site-major matrices [mat][site][state] of float32 log10 posteriors --
+ *              exactly the values raxmlng_reader::read_node produces (ar.cpp:257-260; AA columns
+ *              already in IPK order, ar.cpp:232-234).  Host pointer.
+ *   mat_group  [n_mats] branch id of each matrix = original post-order id
+ *              (explore_kmers: _extended_mapping.at(node_group[0]), db_builder.cpp:613).
+ *              Matrices with equal ids form one group (X0, X1 of a branch) in first-seen order.
+ *   k, log_eps k-mer length and log10 score threshold (db_builder.cpp:640).
+ *
+ * Result (ipkgpu_result_* accessors): for every distinct branch id, the max-reduced set
+ * {(key, score)} identical to group_map after explore_group (db_builder.cpp:685), keys packed
+ * bits-per-symbol as at pk_compute.cpp:96-104, sorted ascending within the group (the
+ * reference's order is hash order), plus the number of scored phylo-k-mers (the reference's
+ * `count`, db_builder.cpp:664).
+ *
+ * Errors: IPKGPU_ERR_INVALID if sigma not in {4, 20}, k < 2, k > ipkgpu_max_k(sigma) or
+ * sites < k (the reference reads out of range there, window.cpp:164-182; we reject).
+ */
+int ipkgpu_score_groups(ipkgpu_ctx* ctx, const float* logp, uint32_t n_mats, uint32_t sites,
+                        uint32_t sigma, const uint32_t* mat_group, uint32_t k, float log_eps,
+                        ipkgpu_result** out);
+
+/* Same, with `logp` already resident in device memory (the measured configuration: no PCIe in
+ * the timed region).  mat_group stays a host pointer.  The call returns after the device work
+ * has completed; results stay in device memory until an accessor asks for a host copy. */
+int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t n_mats,
+                               uint32_t sites, uint32_t sigma, const uint32_t* mat_group,
+                               uint32_t k, float log_eps, ipkgpu_result** out);
+
+/* ---- result accessors -------------------------------------------------------------------- */
+
+uint32_t ipkgpu_result_num_groups(const ipkgpu_result* r);
+/* [num_groups] branch ids in first-seen order (the order explore_kmers appends groups). */
+const uint32_t* ipkgpu_result_group_ids(const ipkgpu_result* r);
+/* [num_groups + 1] CSR offsets into keys/scores. */
+const uint64_t* ipkgpu_result_offsets(const ipkgpu_result* r);
+/* Total scored phylo-k-mers (sum over windows of |DCLA result|; db_builder.cpp:664,697). */
+uint64_t ipkgpu_result_emitted(const ipkgpu_result* r);
+/* Host copies (made on first use; NULL on failure) and the device-resident arrays. */
+const uint32_t* ipkgpu_result_keys(ipkgpu_result* r);
+const float* ipkgpu_result_scores(ipkgpu_result* r);
+const uint32_t* ipkgpu_result_keys_device(const ipkgpu_result* r);
+const float* ipkgpu_result_scores_device(const ipkgpu_result* r);
+/* HIP-event timings of the call that produced r (milliseconds; see IPKGPU_T_*). */
+double ipkgpu_result_time_ms(const ipkgpu_result* r, int which);
+void ipkgpu_result_free(ipkgpu_result* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPKGPU_H */

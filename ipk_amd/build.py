@@ -1,0 +1,35 @@
+"""Builds the in-tree HIP shared libraries for gfx950 (hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libipkgpu.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    hdrs = [os.path.join(HERE, "..", "include", "ipkgpu.h")]
+    if force or _stale(LIB, srcs + hdrs):
+        units = [s for s in srcs if s.endswith(".hip")]
+        cmd = [HIPCC] + FLAGS + ["-o", LIB] + units
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,229 @@
+"""ctypes binding of libipkgpu.so (include/ipkgpu.h).
+
+Mirrors the seam of ipk/src/db_builder.cpp:576-698: ``Engine.score_groups`` takes the ghost-node
+matrices of a batch of branch groups and returns, per branch id, the max-reduced (key, score) set
+that ``explore_group`` leaves in ``group_map`` (db_builder.cpp:685), plus the number of scored
+phylo-k-mers (the reference's ``count``, db_builder.cpp:664).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libipkgpu.so")
+_lib = None
+
+T_TOTAL, T_PREFIX, T_SCORE, T_COMPACT, T_SCORE_LAUNCHES = range(5)
+
+# every symbol include/ipkgpu.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "ipkgpu_create", "ipkgpu_destroy", "ipkgpu_last_error", "ipkgpu_set_option",
+    "ipkgpu_log_threshold", "ipkgpu_bits_per_symbol", "ipkgpu_kmer_batch", "ipkgpu_max_k",
+    "ipkgpu_score_groups", "ipkgpu_score_groups_device",
+    "ipkgpu_result_num_groups", "ipkgpu_result_group_ids", "ipkgpu_result_offsets",
+    "ipkgpu_result_emitted", "ipkgpu_result_keys", "ipkgpu_result_scores",
+    "ipkgpu_result_keys_device", "ipkgpu_result_scores_device", "ipkgpu_result_time_ms",
+    "ipkgpu_result_free",
+]
+
+
+class IpkGpuError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"ipkgpu error {code}: {message}")
+        self.code = code
+
+
+def load_library():
+    """Loads libipkgpu.so (fails loudly if the HIP extension has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} is missing: build it with `python -m ipk_amd.build` "
+                          "(there is no CPU fallback)")
+    # torch ships its own HIP runtime under the same SONAME; import it first so that one copy
+    # of libamdhip64 serves both torch tensors and this library.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
+    L = C.CDLL(_LIB_PATH)
+    f32p, u32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.ipkgpu_create.restype = C.c_int
+    L.ipkgpu_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.ipkgpu_destroy.restype = None
+    L.ipkgpu_destroy.argtypes = [C.c_void_p]
+    L.ipkgpu_last_error.restype = C.c_char_p
+    L.ipkgpu_last_error.argtypes = [C.c_void_p]
+    L.ipkgpu_set_option.restype = C.c_int
+    L.ipkgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.ipkgpu_log_threshold.restype = C.c_float
+    L.ipkgpu_log_threshold.argtypes = [C.c_float, C.c_uint32, C.c_uint32]
+    L.ipkgpu_bits_per_symbol.restype = C.c_uint32
+    L.ipkgpu_bits_per_symbol.argtypes = [C.c_uint32]
+    L.ipkgpu_kmer_batch.restype = C.c_size_t
+    L.ipkgpu_kmer_batch.argtypes = [C.c_uint32, C.c_size_t]
+    L.ipkgpu_max_k.restype = C.c_uint32
+    L.ipkgpu_max_k.argtypes = [C.c_uint32]
+    for name in ("ipkgpu_score_groups", "ipkgpu_score_groups_device"):
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32,
+                       C.c_float, C.POINTER(C.c_void_p)]
+    L.ipkgpu_result_num_groups.restype = C.c_uint32
+    L.ipkgpu_result_num_groups.argtypes = [C.c_void_p]
+    L.ipkgpu_result_group_ids.restype = u32p
+    L.ipkgpu_result_group_ids.argtypes = [C.c_void_p]
+    L.ipkgpu_result_offsets.restype = u64p
+    L.ipkgpu_result_offsets.argtypes = [C.c_void_p]
+    L.ipkgpu_result_emitted.restype = C.c_uint64
+    L.ipkgpu_result_emitted.argtypes = [C.c_void_p]
+    L.ipkgpu_result_keys.restype = u32p
+    L.ipkgpu_result_keys.argtypes = [C.c_void_p]
+    L.ipkgpu_result_scores.restype = f32p
+    L.ipkgpu_result_scores.argtypes = [C.c_void_p]
+    L.ipkgpu_result_keys_device.restype = C.c_void_p
+    L.ipkgpu_result_keys_device.argtypes = [C.c_void_p]
+    L.ipkgpu_result_scores_device.restype = C.c_void_p
+    L.ipkgpu_result_scores_device.argtypes = [C.c_void_p]
+    L.ipkgpu_result_time_ms.restype = C.c_double
+    L.ipkgpu_result_time_ms.argtypes = [C.c_void_p, C.c_int]
+    L.ipkgpu_result_free.restype = None
+    L.ipkgpu_result_free.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def log_threshold(omega, sigma, k):
+    return float(load_library().ipkgpu_log_threshold(C.c_float(omega), sigma, k))
+
+
+def bits_per_symbol(sigma):
+    return int(load_library().ipkgpu_bits_per_symbol(sigma))
+
+
+def kmer_batch(key, n_ranges):
+    return int(load_library().ipkgpu_kmer_batch(key, n_ranges))
+
+
+def max_k(sigma):
+    return int(load_library().ipkgpu_max_k(sigma))
+
+
+class Result:
+    """Owner of an ipkgpu_result (CSR of per-branch (key, score) sets)."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+        n = lib.ipkgpu_result_num_groups(handle)
+        self.group_ids = np.ctypeslib.as_array(lib.ipkgpu_result_group_ids(handle), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        self.offsets = np.ctypeslib.as_array(lib.ipkgpu_result_offsets(handle), shape=(n + 1,)).copy()
+        self.emitted = int(lib.ipkgpu_result_emitted(handle))
+
+    @property
+    def num_entries(self):
+        return int(self.offsets[-1])
+
+    def time_ms(self, which):
+        return float(self._lib.ipkgpu_result_time_ms(self._h, which))
+
+    def keys(self):
+        n = self.num_entries
+        if n == 0:
+            return np.zeros(0, np.uint32)
+        p = self._lib.ipkgpu_result_keys(self._h)
+        if not p:
+            raise IpkGpuError(2, "device-to-host copy of keys failed")
+        return np.ctypeslib.as_array(p, shape=(n,))
+
+    def scores(self):
+        n = self.num_entries
+        if n == 0:
+            return np.zeros(0, np.float32)
+        p = self._lib.ipkgpu_result_scores(self._h)
+        if not p:
+            raise IpkGpuError(2, "device-to-host copy of scores failed")
+        return np.ctypeslib.as_array(p, shape=(n,))
+
+    def keys_device_ptr(self):
+        return self._lib.ipkgpu_result_keys_device(self._h)
+
+    def scores_device_ptr(self):
+        return self._lib.ipkgpu_result_scores_device(self._h)
+
+    def group(self, i):
+        """(keys, scores) of the i-th group in first-seen order (host copies)."""
+        a, b = int(self.offsets[i]), int(self.offsets[i + 1])
+        return self.keys()[a:b], self.scores()[a:b]
+
+    def free(self):
+        if self._h:
+            self._lib.ipkgpu_result_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One scoring context on one GPU (one process per GPU)."""
+
+    def __init__(self, device_id=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.ipkgpu_create(device_id, C.byref(h))
+        if rc != 0:
+            raise IpkGpuError(rc, self._lib.ipkgpu_last_error(None).decode())
+        self._h = h
+
+    def _err(self, rc):
+        return IpkGpuError(rc, self._lib.ipkgpu_last_error(self._h).decode())
+
+    def set_option(self, name, value):
+        rc = self._lib.ipkgpu_set_option(self._h, name.encode(), int(value))
+        if rc != 0:
+            raise self._err(rc)
+
+    def score_groups(self, logp, mat_group, k, log_eps, sigma=None, sites=None, n_mats=None):
+        """logp: numpy float32 [n_mats, sites, sigma] (host path) or a torch CUDA tensor / raw
+        device pointer with explicit n_mats/sites/sigma (device path)."""
+        mat_group = np.ascontiguousarray(mat_group, dtype=np.uint32)
+        out = C.c_void_p()
+        gp = mat_group.ctypes.data_as(C.POINTER(C.c_uint32))
+        if isinstance(logp, np.ndarray):
+            logp = np.ascontiguousarray(logp, dtype=np.float32)
+            n_mats, sites, sigma = logp.shape
+            if mat_group.shape != (n_mats,):
+                raise ValueError("mat_group must have one branch id per matrix")
+            rc = self._lib.ipkgpu_score_groups(self._h, logp.ctypes.data_as(C.c_void_p), n_mats, sites, sigma,
+                                               gp, k, C.c_float(log_eps), C.byref(out))
+        else:
+            if hasattr(logp, "data_ptr"):
+                if not logp.is_cuda or not logp.is_contiguous() or logp.dtype.itemsize != 4:
+                    raise ValueError("device path needs a contiguous float32 CUDA tensor")
+                n_mats, sites, sigma = logp.shape
+                ptr = logp.data_ptr()
+            else:
+                ptr = int(logp)
+            if mat_group.shape != (n_mats,):
+                raise ValueError("mat_group must have one branch id per matrix")
+            rc = self._lib.ipkgpu_score_groups_device(self._h, C.c_void_p(ptr), n_mats, sites, sigma,
+                                                      gp, k, C.c_float(log_eps), C.byref(out))
+        if rc != 0:
+            raise self._err(rc)
+        return Result(self._lib, out)
+
+    def close(self):
+        if self._h:
+            self._lib.ipkgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,148 @@
+"""GPU suite: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import ipk_amd
+from ipk_amd.synth import synth_matrices
+from oracle import ipk_oracle as co
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def check_against_oracle(engine, mats, mat_group, k, eps, device=False):
+    mats = np.ascontiguousarray(mats, dtype=np.float32)
+    mat_group = np.asarray(mat_group, dtype=np.uint32)
+    if device:
+        import torch
+        res = engine.score_groups(torch.from_numpy(mats).cuda(), mat_group, k, eps)
+    else:
+        res = engine.score_groups(mats, mat_group, k, eps)
+    order = list(dict.fromkeys(mat_group.tolist()))               # first-seen order
+    assert res.group_ids.tolist() == order
+    total_emitted = 0
+    for gi, gid in enumerate(order):
+        keys, scores, emitted = co.explore_group(mats[mat_group == gid], k, eps)
+        gk, gs = res.group(gi)
+        assert np.array_equal(gk, keys), f"group {gid}: key sets differ ({len(gk)} vs {len(keys)})"
+        assert np.array_equal(gs.view(np.uint32), scores.view(np.uint32)), f"group {gid}: score bits differ"
+        total_emitted += emitted
+    assert res.emitted == total_emitted
+    res.free()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_fixtures(engine, path):
+    z = np.load(path)
+    mats, k, eps, mpg, ng = z["logp"], int(z["k"]), float(z["eps"]), int(z["mats_per_group"]), int(z["n_groups"])
+    groups = np.repeat(np.arange(ng, dtype=np.uint32) + 7, mpg)
+    res = engine.score_groups(mats, groups, k, eps)
+    assert res.emitted == sum(int(z[f"emitted_{g}"]) for g in range(ng))
+    for g in range(ng):
+        gk, gs = res.group(g)
+        assert np.array_equal(gk, z[f"keys_{g}"])
+        assert np.array_equal(gs.view(np.uint32), z[f"score_bits_{g}"])
+    res.free()
+
+
+@pytest.mark.parametrize("k", list(range(2, 13)))
+def test_dna_all_k(engine, k):
+    mats = synth_matrices(4, 48, 4, 0.1, 200 + k)
+    check_against_oracle(engine, mats, [5, 5, 9, 9], k, co.log_threshold(1.5, 4, k))
+
+
+@pytest.mark.parametrize("k", list(range(2, 7)))
+def test_aa_all_k(engine, k):
+    mats = synth_matrices(3, 20, 20, 0.03, 300 + k)
+    check_against_oracle(engine, mats, [2, 2, 4], k, co.log_threshold(1.5, 20, k))
+
+
+def test_group_order_and_interleaving(engine):
+    # branch ids arbitrary, matrices of a group not adjacent, a single-matrix group (INNER_ONLY ghosts)
+    mats = synth_matrices(7, 40, 4, 0.1, 77)
+    check_against_oracle(engine, mats, [900, 3, 900, 41, 3, 41, 12], 8, co.log_threshold(1.5, 4, 8), device=True)
+
+
+def test_sites_equal_k_and_ragged_tile(engine):
+    mats = synth_matrices(2, 10, 4, 0.3, 5)
+    check_against_oracle(engine, mats, [0, 0], 10, co.log_threshold(1.5, 4, 10))      # one window
+    mats = synth_matrices(2, 64 + 9 + 3, 4, 0.1, 6)                                      # 67 windows: ragged 2nd tile
+    check_against_oracle(engine, mats, [0, 1], 10, co.log_threshold(1.5, 4, 10))
+
+
+def test_rejects_bad_arguments(engine):
+    mats = synth_matrices(2, 8, 4, 0.3, 5)
+    with pytest.raises(ipk_amd.IpkGpuError):
+        engine.score_groups(mats, [0, 0], 10, -4.0)        # sites < k (unguarded in the reference; rejected here)
+    with pytest.raises(ipk_amd.IpkGpuError):
+        engine.score_groups(mats, [0, 0], 13, -4.0)        # k above the supported maximum
+    with pytest.raises(ipk_amd.IpkGpuError):
+        engine.score_groups(np.zeros((1, 8, 5), np.float32), [0], 4, -4.0)   # unsupported alphabet
+
+
+def test_big_list_fallback_dna(engine):
+    # a permissive threshold makes the half lists exceed the fast path's capacity (4^5 > 256):
+    # those windows are re-done by the big-list kernel; results must not change
+    mats = synth_matrices(2, 14, 4, 1.0, 9)
+    check_against_oracle(engine, mats, [0, 0], 10, -9.0)
+    mats = synth_matrices(1, 14, 4, 1.0, 10)
+    check_against_oracle(engine, mats, [0], 12, -12.0)
+
+
+def test_big_list_fallback_aa(engine):
+    mats = synth_matrices(1, 8, 20, 0.3, 11)
+    check_against_oracle(engine, mats, [0], 6, -9.5)
+
+
+def test_zero_probabilities_and_dead_columns(engine):
+    mats = synth_matrices(2, 40, 4, 0.2, 21)
+    mats[0, 7, 2] = -np.inf            # log10(0)
+    mats[1, 20, :] = -np.inf           # dead column: later prefix sums are -inf, bounds become NaN
+    check_against_oracle(engine, mats, [0, 1], 8, co.log_threshold(1.5, 4, 8))
+
+
+def test_flat_columns_ties(engine):
+    # identical columns: many equal scores, exercises max-reduce ties across windows and matrices
+    col = np.log10(np.array([0.4, 0.3, 0.2, 0.1], dtype=np.float32))
+    mats = np.tile(col, (2, 30, 1)).astype(np.float32)
+    check_against_oracle(engine, mats, [0, 0], 6, co.log_threshold(1.0, 4, 6))
+
+
+def test_idempotent_and_sorted(engine):
+    mats = synth_matrices(6, 500, 4, 0.05, 31)
+    groups = [0, 0, 1, 1, 2, 2]
+    eps = co.log_threshold(1.5, 4, 10)
+    a = engine.score_groups(mats, groups, 10, eps)
+    b = engine.score_groups(mats, groups, 10, eps)
+    assert a.emitted == b.emitted and np.array_equal(a.offsets, b.offsets)
+    assert np.array_equal(a.keys(), b.keys()) and np.array_equal(a.scores().view(np.uint32), b.scores().view(np.uint32))
+    for g in range(3):
+        k_, s_ = a.group(g)
+        assert np.all(np.diff(k_.astype(np.int64)) > 0)          # strictly ascending: no duplicate keys
+        assert np.all(s_ > eps)                                  # every kept score passed the threshold
+    a.free(); b.free()
+
+
+def test_workspace_batching(engine):
+    # force several batches of groups (table = 4^8 * 4 B = 256 KiB per group)
+    mats = synth_matrices(10, 60, 4, 0.1, 41)
+    groups = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]
+    engine.set_option("workspace_bytes", 2 * 4 ** 8 * 4)
+    try:
+        check_against_oracle(engine, mats, groups, 8, co.log_threshold(1.5, 4, 8))
+    finally:
+        engine.set_option("workspace_bytes", 8 << 30)
+
+
+def test_full_size_matrices_sampled(engine):
+    """BASELINE cfg2 shape (10 000 sites, k=10) on a few groups: bit-exact vs the oracle."""
+    mats = synth_matrices(6, 10000, 4, 0.05, 42)
+    check_against_oracle(engine, mats, [0, 0, 1, 1, 2, 2], 10, co.log_threshold(1.5, 4, 10), device=True)
+
+
+def test_full_size_aa_sampled(engine):
+    mats = synth_matrices(2, 3000, 20, 0.03, 43)
+    check_against_oracle(engine, mats, [0, 0], 6, co.log_threshold(1.5, 20, 6), device=True)
