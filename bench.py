@@ -71,6 +71,8 @@ def main():
     t_gen = time.time() - t0
 
     eng = ipk_amd.Engine(local_rank)
+    if os.environ.get("IPKGPU_VARIANT"):
+        eng.set_option("variant", int(os.environ["IPKGPU_VARIANT"]))   # diagnostics only
 
     def barrier():
         if world > 1:

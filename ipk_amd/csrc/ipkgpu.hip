@@ -95,6 +95,7 @@ struct ScoreParams {
     unsigned long long* emitted;
     unsigned long long* ovf_queue; // (mat << 32 | window start) of windows whose lists overflowed
     uint32_t* ovf_count;
+    uint32_t flags;               // bit 0 (diagnostic builds of bench only): skip the table update
 };
 
 // One window: build both half lists, then the final filtered cross product goes straight into the
@@ -102,7 +103,7 @@ struct ScoreParams {
 // (nothing has been emitted for the window in that case).
 template <int SIGMA, int K, int CAP>
 __device__ __forceinline__ bool score_window(const WinCtx& c, float eps, uint2* scratch,
-                                             uint32_t* __restrict__ tab, uint32_t& emitted)
+                                             uint32_t* __restrict__ tab, uint32_t& emitted, bool no_put = false)
 {
     if constexpr (Geo<SIGMA, K, CAP>::DIRECT) {
         const uint32_t lane = lane_id();
@@ -122,7 +123,7 @@ __device__ __forceinline__ bool score_window(const WinCtx& c, float eps, uint2* 
         for_each_pair(L, nL, R, nR, [&](bool valid, uint2 a, uint2 b) {
             const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
             const bool pass = valid && (s > eps);                              // :91
-            if (pass) atomicMax(tab + (a.x * mulR + b.x), enc_score_bits(__float_as_uint(s)));
+            if (pass && !no_put) atomicMax(tab + (a.x * mulR + b.x), enc_score_bits(__float_as_uint(s)));
             cnt += (uint32_t)__popcll(__ballot(pass));
         });
         emitted += cnt;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
     uint32_t emitted = 0;
     for (uint32_t w = wave; w < nw; w += NW) {
         WinCtx c{cols, best, w};
-        if (!score_window<SIGMA, K, CAP>(c, p.eps, scratch, tab, emitted)) {
+        if (!score_window<SIGMA, K, CAP>(c, p.eps, scratch, tab, emitted, (p.flags & 1u) != 0)) {
             if (lane_id() == 0) {
                 const uint32_t q = atomicAdd(p.ovf_count, 1u);
                 p.ovf_queue[q] = ((unsigned long long)mat << 32) | (unsigned long long)(t0 + w);
@@ -649,6 +650,7 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
         p.emitted = d_emitted;
         p.ovf_queue = (unsigned long long*)ctx->ovfq;
         p.ovf_count = d_ovf_count;
+        p.flags = (uint32_t)(ctx->opt_variant == 99 ? 1 : 0);
 
         hipEvent_t s0 = new_event(), s1 = new_event(), c1 = new_event();
         HIP_TRY_R(hipMemsetAsync(ctx->table, 0, (size_t)gb * table_bytes, ctx->stream));
