@@ -29,6 +29,8 @@ extern "C" {
 
 typedef struct ipkgpu_ctx ipkgpu_ctx;
 typedef struct ipkgpu_result ipkgpu_result;
+typedef struct ipkgpu_parts ipkgpu_parts;
+typedef struct ipkgpu_db ipkgpu_db;
 
 enum {
     IPKGPU_OK = 0,
@@ -131,6 +133,61 @@ const float* ipkgpu_result_scores_device(const ipkgpu_result* r);
 /* HIP-event timings of the call that produced r (milliseconds; see IPKGPU_T_*). */
 double ipkgpu_result_time_ms(const ipkgpu_result* r, int which);
 void ipkgpu_result_free(ipkgpu_result* r);
+
+/* ---- key-major database parts and the k-mer-keyed merge (multi-GPU exchange step) ---------------- */
+
+/*
+ * Same scoring pass as ipkgpu_score_groups_device, but the result is delivered KEY-major and split
+ * by owner -- the device analogue of the insertion loop at db_builder.cpp:685-694
+ * (`_phylo_kmer_db.unsafe_insert(kmer, {branch, score})`, group after group) and of the on-disk
+ * path's k-mer-keyed partition (kmer_batch, branch_group.cpp:104-107; merge_batch :45-70).
+ *
+ * Owner of a k-mer = dense_code % n_owners, where dense_code is the base-sigma value of the k-mer
+ * (for DNA this IS the packed key, so owner = kmer_batch(key, n_owners)).  For owner o, key slot q
+ * stands for dense code q * n_owners + o; slots = ceil(sigma^k / n_owners) per owner (zero padded).
+ *
+ *   counts   u32 [n_owners][slots]   number of (branch, score) entries of the key
+ *   entries  {u32 branch, f32 score} owner-major, then ascending key, then group (first-seen) order
+ *   owner_offsets  u64 [n_owners + 1] (host) entry offset of every owner's block
+ *
+ * With n_owners = world size, block o is what this rank sends to rank o (all-to-all over RCCL);
+ * ipkgpu_merge_parts on the receiver concatenates, per key, the blocks of ranks 0..P-1.
+ */
+int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t n_mats, uint32_t sites,
+                                        uint32_t sigma, const uint32_t* mat_group, uint32_t k, float log_eps,
+                                        uint32_t n_owners, ipkgpu_parts** out);
+uint32_t ipkgpu_parts_num_owners(const ipkgpu_parts* p);
+uint64_t ipkgpu_parts_slots(const ipkgpu_parts* p);
+const uint32_t* ipkgpu_parts_counts_device(const ipkgpu_parts* p);
+const void* ipkgpu_parts_entries_device(const ipkgpu_parts* p);
+const uint64_t* ipkgpu_parts_owner_offsets(const ipkgpu_parts* p);
+uint64_t ipkgpu_parts_emitted(const ipkgpu_parts* p);
+double ipkgpu_parts_time_ms(const ipkgpu_parts* p, int which);
+void ipkgpu_parts_free(ipkgpu_parts* p);
+
+/*
+ * Merges, for one owner, the blocks received from n_sources ranks (or produced by n_sources batches):
+ *   counts_dev      u32 [n_sources][slots] (device), source-major
+ *   entries_dev     the sources' entry blocks (device); source s starts at entry source_offsets[s]
+ *   source_offsets  u64 [n_sources] (host)
+ * Result: this owner's shard of the phylo-k-mer database -- keys (IPK bit-packed codes, ascending),
+ * key_offsets [num_keys + 1], entries {branch, score} with each key's entries in source order then
+ * group order, i.e. the order the reference appends them (db_builder.cpp:606-618,685-694).
+ */
+int ipkgpu_merge_parts(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, uint32_t n_owners,
+                       uint32_t n_sources, const uint32_t* counts_dev, const void* entries_dev,
+                       const uint64_t* source_offsets, ipkgpu_db** out);
+uint64_t ipkgpu_db_num_keys(const ipkgpu_db* d);
+uint64_t ipkgpu_db_num_entries(const ipkgpu_db* d);
+/* host copies (made on first use): keys u32[num_keys], key_offsets u64[num_keys+1], entries u32[num_entries][2] */
+const uint32_t* ipkgpu_db_keys(ipkgpu_db* d);
+const uint64_t* ipkgpu_db_key_offsets(ipkgpu_db* d);
+const uint32_t* ipkgpu_db_entries(ipkgpu_db* d);
+const uint32_t* ipkgpu_db_keys_device(const ipkgpu_db* d);
+const uint64_t* ipkgpu_db_key_offsets_device(const ipkgpu_db* d);
+const void* ipkgpu_db_entries_device(const ipkgpu_db* d);
+double ipkgpu_db_time_ms(const ipkgpu_db* d);
+void ipkgpu_db_free(ipkgpu_db* d);
 
 #ifdef __cplusplus
 }

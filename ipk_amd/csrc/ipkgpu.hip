@@ -26,294 +26,25 @@
 
 #include "../../include/ipkgpu.h"
 #include "dcla_device.hpp"
+#include "kernels_score.hpp"
+#include "kernels_compact.hpp"
+#include "kernels_keymajor.hpp"
 
 using namespace ipkgpu;
 
 // =============================================================================================
-// kernels
-// =============================================================================================
-
-// ---- matrix::preprocess (window.cpp:16-27): best[0] = 0, best[j+1] = best[j] + max_i m[j][i] ---
-// One workgroup per matrix.  Column maxima are computed by all lanes (coalesced), the running sum
-// is accumulated by ONE lane in site order -- a parallel scan would round differently, and the
-// rounding noise of this array is part of the reference semantics.
-template <int SIGMA>
-__global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict__ logp, uint32_t sites,
-                                                         float* __restrict__ best)
-{
-    constexpr int CH = 4096;
-    __shared__ float cm[CH];
-    __shared__ float carry;
-    const uint32_t mat = blockIdx.x;
-    const float* m = logp + (size_t)mat * sites * SIGMA;
-    float* b = best + (size_t)mat * (sites + 1);
-    if (threadIdx.x == 0) { carry = 0.0f; b[0] = 0.0f; }
-    for (uint32_t c0 = 0; c0 < sites; c0 += CH) {
-        const uint32_t n = min((uint32_t)CH, sites - c0);
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-            const float4* col = reinterpret_cast<const float4*>(m + (size_t)(c0 + j) * SIGMA);
-            float largest;
-            {
-                const float4 v = col[0];
-                largest = v.x;                                  // std::max_element: first largest
-                if (largest < v.y) largest = v.y;
-                if (largest < v.z) largest = v.z;
-                if (largest < v.w) largest = v.w;
-            }
-#pragma unroll
-            for (int q = 1; q < SIGMA / 4; ++q) {
-                const float4 v = col[q];
-                if (largest < v.x) largest = v.x;
-                if (largest < v.y) largest = v.y;
-                if (largest < v.z) largest = v.z;
-                if (largest < v.w) largest = v.w;
-            }
-            cm[j] = largest;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float acc = carry;
-#pragma unroll 8
-            for (uint32_t j = 0; j < n; ++j) { acc += cm[j]; cm[j] = acc; }
-            carry = acc;
-        }
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) b[c0 + j + 1] = cm[j];
-        __syncthreads();
-    }
-}
-
-struct ScoreParams {
-    const float* logp;            // [n_mats][sites][SIGMA]
-    const float* best;            // [n_mats][sites+1]
-    const uint32_t* mat_list;     // matrices of this batch (indices into logp/best)
-    const uint32_t* mat_slot;     // [n_mats] table slot of each matrix within this batch
-    uint32_t n_batch_mats, sites, nwin, tiles_per_mat;
-    float eps;
-    uint32_t* table;              // [slots][table_size]
-    uint64_t table_size;
-    unsigned long long* emitted;
-    unsigned long long* ovf_queue; // (mat << 32 | window start) of windows whose lists overflowed
-    uint32_t* ovf_count;
-    uint32_t flags;               // bit 0 (diagnostic builds of bench only): skip the table update
-};
-
-// One window: build both half lists, then the final filtered cross product goes straight into the
-// group's max table (ipk::put, branch_group.cpp:88-101).  Returns false if a list overflowed CAP
-// (nothing has been emitted for the window in that case).
-template <int SIGMA, int K, int CAP>
-__device__ __forceinline__ bool score_window(const WinCtx& c, float eps, uint2* scratch,
-                                             uint32_t* __restrict__ tab, uint32_t& emitted, bool no_put = false)
-{
-    if constexpr (Geo<SIGMA, K, CAP>::DIRECT) {
-        const uint32_t lane = lane_id();
-        float s = 0.f;
-        bool pass = false;
-        if (lane < Geo<SIGMA, K, CAP>::FULL) pass = Direct<SIGMA, 0, K>::eval(c, eps, lane, s);
-        if (pass) atomicMax(tab + lane, enc_score_bits(__float_as_uint(s)));
-        emitted += (uint32_t)__popcll(__ballot(pass));
-        return true;
-    } else {
-        const uint2 *L, *R;
-        uint32_t nL, nR;
-        if (!build_halves<SIGMA, K, CAP>(c, eps, scratch, L, nL, R, nR)) return false;
-        if (nL == 0 || nR == 0) return true;
-        constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
-        uint32_t cnt = 0;
-        for_each_pair(L, nL, R, nR, [&](bool valid, uint2 a, uint2 b) {
-            const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
-            const bool pass = valid && (s > eps);                              // :91
-            if (pass && !no_put) atomicMax(tab + (a.x * mulR + b.x), enc_score_bits(__float_as_uint(s)));
-            cnt += (uint32_t)__popcll(__ballot(pass));
-        });
-        emitted += cnt;
-        return true;
-    }
-}
-
-template <int SIGMA, int K, int TW>
-struct TileGeo {
-    static constexpr int TC = TW + K - 1;                 // columns a tile of TW windows touches
-    static constexpr int COLS_F = TC * SIGMA;             // floats (multiple of 4)
-    static constexpr int BEST_F = ((TC + 1 + 3) / 4) * 4;
-    static constexpr int HEAD_BYTES = (COLS_F + BEST_F) * 4;
-};
-
-// Fast path: a workgroup stages the columns of TW consecutive windows of one matrix in LDS
-// (coalesced 16-byte loads), its NW wavefronts take windows round-robin.
-template <int SIGMA, int K, int CAP, int TW, int NW>
-__global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    using TG = TileGeo<SIGMA, K, TW>;
-    float* cols = reinterpret_cast<float*>(smem);
-    float* best = cols + TG::COLS_F;
-    uint2* scratch_all = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
-    constexpr uint32_t WS = wave_scratch_entries<SIGMA, K, CAP>();
-
-    const uint32_t bm = blockIdx.x / p.tiles_per_mat;
-    const uint32_t tile = blockIdx.x - bm * p.tiles_per_mat;
-    const uint32_t mat = p.mat_list[bm];
-    const uint32_t t0 = tile * TW;
-    const uint32_t nw = min((uint32_t)TW, p.nwin - t0);
-    const uint32_t ncol = nw + K - 1;
-
-    {
-        const float4* src = reinterpret_cast<const float4*>(p.logp + ((size_t)mat * p.sites + t0) * SIGMA);
-        float4* dst = reinterpret_cast<float4*>(cols);
-        const uint32_t n4 = ncol * (SIGMA / 4);
-        for (uint32_t i = threadIdx.x; i < n4; i += NW * 64) dst[i] = src[i];
-        const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + t0;
-        for (uint32_t i = threadIdx.x; i <= ncol; i += NW * 64) best[i] = bsrc[i];
-    }
-    __syncthreads();
-
-    const uint32_t wave = threadIdx.x >> 6;
-    uint2* scratch = scratch_all + (size_t)wave * WS;
-    uint32_t* tab = p.table + (size_t)p.mat_slot[mat] * p.table_size;
-    uint32_t emitted = 0;
-    for (uint32_t w = wave; w < nw; w += NW) {
-        WinCtx c{cols, best, w};
-        if (!score_window<SIGMA, K, CAP>(c, p.eps, scratch, tab, emitted, (p.flags & 1u) != 0)) {
-            if (lane_id() == 0) {
-                const uint32_t q = atomicAdd(p.ovf_count, 1u);
-                p.ovf_queue[q] = ((unsigned long long)mat << 32) | (unsigned long long)(t0 + w);
-            }
-        }
-    }
-    if (lane_id() == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
-}
-
-// Big-list path: one wavefront per workgroup with worst-case list capacity (sigma^(k/2) entries per
-// half list), walking the queue of windows the fast path could not hold.  Every wave reaches the
-// loop exit: the queue length is fixed before this kernel starts.
-template <int SIGMA, int K>
-__global__ __launch_bounds__(64) void score_overflow_kernel(ScoreParams p)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int CAPF = 1 << 30;
-    using TG = TileGeo<SIGMA, K, 1>;
-    float* cols = reinterpret_cast<float*>(smem);
-    float* best = cols + TG::COLS_F;
-    uint2* scratch = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
-    const uint32_t n = *p.ovf_count;
-    uint32_t emitted = 0;
-    for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
-        const unsigned long long e = p.ovf_queue[q];
-        const uint32_t mat = (uint32_t)(e >> 32), start = (uint32_t)e;
-        const float* src = p.logp + ((size_t)mat * p.sites + start) * SIGMA;
-        for (uint32_t i = threadIdx.x; i < K * SIGMA; i += 64) cols[i] = src[i];
-        const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + start;
-        for (uint32_t i = threadIdx.x; i <= K; i += 64) best[i] = bsrc[i];
-        wave_lds_sync();
-        WinCtx c{cols, best, 0};
-        uint32_t* tab = p.table + (size_t)p.mat_slot[mat] * p.table_size;
-        score_window<SIGMA, K, CAPF>(c, p.eps, scratch, tab, emitted);
-        wave_lds_sync();
-    }
-    if (lane_id() == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
-}
-
-// ---- table -> CSR compaction -------------------------------------------------------------------
-constexpr uint32_t CHUNK = 4096;   // table slots per workgroup
-
-__global__ __launch_bounds__(256) void count_chunks_kernel(const uint32_t* __restrict__ table, uint64_t table_size,
-                                                           uint32_t chunks_per_group, uint32_t* __restrict__ counts)
-{
-    __shared__ uint32_t wsum[4];
-    const uint32_t g = blockIdx.x / chunks_per_group, c = blockIdx.x - g * chunks_per_group;
-    const uint32_t* t = table + (size_t)g * table_size;
-    const uint64_t s0 = (uint64_t)c * CHUNK;
-    const uint32_t n = (uint32_t)min((uint64_t)CHUNK, table_size - s0);
-    uint32_t cnt = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) cnt += (t[s0 + i] != 0u);
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-    if (lane_id() == 0) wsum[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// Exclusive scan of n u32 counts into n+1 u64 offsets (single workgroup; n is ~1e5..1e7).
-__global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __restrict__ counts, uint64_t n,
-                                                           uint64_t base, uint64_t* __restrict__ offsets)
-{
-    __shared__ uint64_t part[1024];
-    const uint64_t per = (n + 1023) / 1024;
-    const uint64_t lo = min(n, (uint64_t)threadIdx.x * per), hi = min(n, lo + per);
-    uint64_t s = 0;
-    for (uint64_t i = lo; i < hi; ++i) s += counts[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t acc = base;
-        for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = acc; acc += v; }
-        offsets[n] = acc;
-    }
-    __syncthreads();
-    uint64_t acc = part[threadIdx.x];
-    for (uint64_t i = lo; i < hi; ++i) { offsets[i] = acc; acc += counts[i]; }
-}
-
-// offsets[g * stride] for g in [0, n) -> out[g]: the per-group CSR offsets of a batch
-__global__ void gather_offsets_kernel(const uint64_t* __restrict__ offsets, uint32_t stride, uint32_t n,
-                                      uint64_t* __restrict__ out)
-{
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n) out[g] = offsets[(size_t)g * stride];
-}
-
-template <int SIGMA>
-__device__ __forceinline__ uint32_t pack_code(uint32_t dense, int k)
-{
-    if constexpr (SIGMA == 4) { (void)k; return dense; }
-    else {
-        constexpr int BITS = 5;
-        uint32_t key = 0;
-        for (int d = 0; d < k; ++d) {                 // last symbol in the lowest bits
-            const uint32_t q = dense / SIGMA;
-            key |= (dense - q * SIGMA) << (BITS * d);
-            dense = q;
-        }
-        return key;
-    }
-}
-
-template <int SIGMA>
-__global__ __launch_bounds__(256) void write_chunks_kernel(const uint32_t* __restrict__ table, uint64_t table_size,
-                                                           uint32_t chunks_per_group, int k,
-                                                           const uint64_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ keys, float* __restrict__ scores)
-{
-    __shared__ uint32_t wcnt[4];
-    const uint32_t g = blockIdx.x / chunks_per_group, c = blockIdx.x - g * chunks_per_group;
-    const uint32_t* t = table + (size_t)g * table_size;
-    const uint64_t s0 = (uint64_t)c * CHUNK;
-    const uint32_t n = (uint32_t)min((uint64_t)CHUNK, table_size - s0);
-    uint64_t out = offsets[blockIdx.x];
-    const uint32_t wave = threadIdx.x >> 6;
-    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
-        const uint32_t i = i0 + threadIdx.x;
-        uint32_t v = 0;
-        if (i < n) v = t[s0 + i];
-        const uint64_t m = __ballot(v != 0u);
-        if (lane_id() == 0) wcnt[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) { const uint32_t x = wcnt[q]; total += x; if (q < wave) before += x; }
-        if (v != 0u) {
-            const uint64_t pos = out + before + mbcnt(m);
-            keys[pos] = pack_code<SIGMA>((uint32_t)(s0 + i), k);
-            scores[pos] = __uint_as_float(dec_score_bits(v));
-        }
-        out += total;
-        __syncthreads();
-    }
-}
-
-// =============================================================================================
 // host side
 // =============================================================================================
+
+namespace {
+
+struct DevBuf {                       // grow-only device workspace
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
 
 struct ipkgpu_ctx {
     int device = 0;
@@ -322,15 +53,8 @@ struct ipkgpu_ctx {
     int64_t workspace_bytes = 0;
     int64_t opt_list_cap = 0;
     int64_t opt_variant = 0;
-    // grow-only cached workspaces
-    void* table = nullptr;      size_t table_cap = 0;
-    void* best = nullptr;       size_t best_cap = 0;
-    void* ovfq = nullptr;       size_t ovfq_cap = 0;
-    void* counts = nullptr;     size_t counts_cap = 0;
-    void* offsets = nullptr;    size_t offsets_cap = 0;
-    void* goff = nullptr;       size_t goff_cap = 0;
-    void* small = nullptr;      // emitted (u64) + ovf_count (u32)
-    void* idx = nullptr;        size_t idx_cap = 0;   // mat_list + mat_slot
+    DevBuf table, best, ovfq, counts, offsets, goff, idx, branch, scan_sums, scan_boff, tmp_a, tmp_b, tmp_c;
+    void* small = nullptr;            // emitted (u64) @0, ovf_count (u32) @16
     int num_cu = 256;
 };
 
@@ -347,6 +71,31 @@ struct ipkgpu_result {
     bool h_keys_ok = false, h_scores_ok = false;
     double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0;
     int score_launches = 0;
+};
+
+struct ipkgpu_parts {
+    ipkgpu_ctx* ctx = nullptr;
+    uint32_t n_owners = 1;
+    uint64_t slots = 0;                       // padded key slots per owner = ceil(sigma^k / n_owners)
+    uint32_t* d_counts = nullptr;             // [n_owners][slots]
+    uint2* d_entries = nullptr;               // owner-major, key-major, group order: (branch, score bits)
+    std::vector<uint64_t> owner_off;          // [n_owners + 1] entry offsets
+    uint64_t emitted = 0;
+    double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0;
+    int score_launches = 0;
+};
+
+struct ipkgpu_db {
+    ipkgpu_ctx* ctx = nullptr;
+    uint64_t n_keys = 0, n_entries = 0;
+    uint32_t* d_keys = nullptr;               // [n_keys] packed codes, ascending
+    uint64_t* d_key_off = nullptr;            // [n_keys + 1]
+    uint2* d_entries = nullptr;               // [n_entries] (branch, score bits)
+    std::vector<uint32_t> h_keys;
+    std::vector<uint64_t> h_key_off;
+    std::vector<uint32_t> h_entries;          // [n_entries][2]
+    bool h_ok = false;
+    double t_merge = 0;
 };
 
 static std::string g_create_err;
@@ -369,15 +118,42 @@ static int fail(ipkgpu_ctx* ctx, int code, const char* fmt, ...)
             return fail(ctx, e_ == hipErrorOutOfMemory ? IPKGPU_ERR_NOMEM : IPKGPU_ERR_HIP,     \
                         "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+#define RC_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
-static int ensure(ipkgpu_ctx* ctx, void** p, size_t* cap, size_t need)
+static int ensure(ipkgpu_ctx* ctx, DevBuf& b, size_t need)
 {
-    if (*cap >= need && *p) return IPKGPU_OK;
-    if (*p) { HIP_TRY(ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
-    HIP_TRY(ctx, hipMalloc(p, need));
-    *cap = need;
+    if (b.cap >= need && b.p) return IPKGPU_OK;
+    if (b.p) { HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    HIP_TRY(ctx, hipMalloc(&b.p, std::max<size_t>(need, 16)));
+    b.cap = std::max<size_t>(need, 16);
     return IPKGPU_OK;
 }
+
+namespace {
+
+// Stream-ordered HIP-event stopwatch; events are destroyed with the object.
+struct Stopwatch {
+    hipStream_t stream;
+    std::vector<hipEvent_t> ev;
+    explicit Stopwatch(hipStream_t s) : stream(s) {}
+    ~Stopwatch() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+    int mark()
+    {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        (void)hipEventRecord(e, stream);
+        ev.push_back(e);
+        return (int)ev.size() - 1;
+    }
+    double ms(int a, int b) const
+    {
+        float t = 0;
+        if (a < 0 || b < 0 || hipEventElapsedTime(&t, ev[a], ev[b]) != hipSuccess) return 0;
+        return t;
+    }
+};
+
+}  // namespace
 
 extern "C" {
 
@@ -417,7 +193,7 @@ int ipkgpu_create(int device_id, ipkgpu_ctx** out)
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ctx->workspace_bytes = (int64_t)(free_b / 2);
     else ctx->workspace_bytes = (int64_t)8 << 30;
     if ((e = hipMalloc(&ctx->small, 64)) != hipSuccess) {
-        hipStreamDestroy(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(nullptr, IPKGPU_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
     }
@@ -428,11 +204,13 @@ int ipkgpu_create(int device_id, ipkgpu_ctx** out)
 void ipkgpu_destroy(ipkgpu_ctx* ctx)
 {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    void* bufs[] = {ctx->table, ctx->best, ctx->ovfq, ctx->counts, ctx->offsets, ctx->goff, ctx->small, ctx->idx};
-    for (void* b : bufs) if (b) hipFree(b);
-    hipStreamDestroy(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
+                      &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c};
+    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    if (ctx->small) (void)hipFree(ctx->small);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -534,14 +312,122 @@ int dispatch_score(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScoreParam
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k (%u/%u)", sigma, k);
 }
 
-struct EventPair {
-    hipEvent_t a = nullptr, b = nullptr;
+}  // namespace
+
+// ---- the scoring pass shared by every output form ---------------------------------------------------
+namespace {
+
+struct Plan {
+    uint32_t n_mats = 0, sites = 0, sigma = 0, k = 0;
+    float eps = 0;
+    std::vector<uint32_t> group_ids;   // first-seen order (group_ghost_ids, db_builder.cpp:524-553)
+    std::vector<uint32_t> slot_of;     // [n_mats] group index of each matrix
+    uint32_t n_groups = 0, nwin = 0, tiles_per_mat = 0, chunks_per_group = 0;
+    uint64_t table_size = 0, gpb = 1;  // slots per group table; groups per batch
 };
+
+int make_plan(ipkgpu_ctx* ctx, const void* logp, uint32_t n_mats, uint32_t sites, uint32_t sigma,
+              const uint32_t* mat_group, uint32_t k, float log_eps, Plan& pl)
+{
+    if (!logp || !mat_group) return fail(ctx, IPKGPU_ERR_INVALID, "null input pointer");
+    if (sigma != 4 && sigma != 20) return fail(ctx, IPKGPU_ERR_INVALID, "unsupported alphabet size %u (4 or 20)", sigma);
+    if (k < 2 || k > ipkgpu_max_k(sigma))
+        return fail(ctx, IPKGPU_ERR_INVALID, "k=%u out of range [2, %u] for sigma=%u", k, ipkgpu_max_k(sigma), sigma);
+    if (n_mats == 0) return fail(ctx, IPKGPU_ERR_INVALID, "no matrices");
+    if (sites < k) return fail(ctx, IPKGPU_ERR_INVALID, "alignment has %u sites, fewer than k=%u", sites, k);
+    pl.n_mats = n_mats; pl.sites = sites; pl.sigma = sigma; pl.k = k; pl.eps = log_eps;
+    pl.slot_of.resize(n_mats);
+    std::unordered_map<uint32_t, uint32_t> index;
+    index.reserve(n_mats);
+    for (uint32_t i = 0; i < n_mats; ++i) {
+        auto it = index.find(mat_group[i]);
+        if (it == index.end()) {
+            it = index.emplace(mat_group[i], (uint32_t)pl.group_ids.size()).first;
+            pl.group_ids.push_back(mat_group[i]);
+        }
+        pl.slot_of[i] = it->second;
+    }
+    pl.n_groups = (uint32_t)pl.group_ids.size();
+    pl.table_size = ipow(sigma, (int)k);
+    pl.chunks_per_group = (uint32_t)((pl.table_size + CHUNK - 1) / CHUNK);
+    pl.gpb = std::max<uint64_t>(1, (uint64_t)ctx->workspace_bytes / (pl.table_size * 4));
+    pl.gpb = std::min<uint64_t>(pl.gpb, pl.n_groups);
+    while (pl.gpb > 1 && pl.gpb * pl.chunks_per_group > 0x7fffffffull) pl.gpb /= 2;
+    pl.nwin = sites - k + 1;
+    pl.tiles_per_mat = (pl.nwin + TW - 1) / TW;
+    return IPKGPU_OK;
+}
+
+int run_prefix(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev)
+{
+    RC_TRY(ensure(ctx, ctx->best, (size_t)pl.n_mats * (pl.sites + 1) * 4));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->small, 0, 64, ctx->stream));
+    if (pl.sigma == 4)
+        hipLaunchKernelGGL(prefix_max_kernel<4>, dim3(pl.n_mats), dim3(256), 0, ctx->stream, logp_dev, pl.sites, ctx->best.as<float>());
+    else
+        hipLaunchKernelGGL(prefix_max_kernel<20>, dim3(pl.n_mats), dim3(256), 0, ctx->stream, logp_dev, pl.sites, ctx->best.as<float>());
+    HIP_TRY(ctx, hipGetLastError());
+    return IPKGPU_OK;
+}
+
+// Scores groups [g0, g0 + gb) into ctx->table ([gb][table_size], zeroed here).
+int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t g0, uint32_t gb,
+                std::vector<uint32_t>& idx_host)
+{
+    const uint32_t n_mats = pl.n_mats;
+    idx_host.resize((size_t)n_mats * 2);
+    uint32_t nb = 0;
+    uint32_t* mat_list_h = idx_host.data();
+    uint32_t* mat_slot_h = idx_host.data() + n_mats;
+    for (uint32_t i = 0; i < n_mats; ++i) {
+        mat_slot_h[i] = 0;
+        if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) { mat_list_h[nb++] = i; mat_slot_h[i] = pl.slot_of[i] - g0; }
+    }
+    RC_TRY(ensure(ctx, ctx->idx, (size_t)n_mats * 8));
+    RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 4));
+    RC_TRY(ensure(ctx, ctx->ovfq, (size_t)nb * pl.nwin * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->idx.p, idx_host.data(), (size_t)n_mats * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // idx_host is pageable and reused by the next batch
+
+    ScoreParams p;
+    p.logp = logp_dev;
+    p.best = ctx->best.as<float>();
+    p.mat_list = ctx->idx.as<uint32_t>();
+    p.mat_slot = ctx->idx.as<uint32_t>() + n_mats;
+    p.n_batch_mats = nb; p.sites = pl.sites; p.nwin = pl.nwin; p.tiles_per_mat = pl.tiles_per_mat;
+    p.eps = pl.eps;
+    p.table = ctx->table.as<uint32_t>();
+    p.table_size = pl.table_size;
+    p.emitted = reinterpret_cast<unsigned long long*>(ctx->small);
+    p.ovf_queue = ctx->ovfq.as<unsigned long long>();
+    p.ovf_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 16);
+    p.flags = (uint32_t)(ctx->opt_variant == 99 ? 1 : 0);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->table.p, 0, (size_t)gb * pl.table_size * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
+    return dispatch_score(ctx, pl.sigma, pl.k, p);
+}
+
+// out[0..n] = base + exclusive scan of in[0..n)   (u32 -> u64)
+int scan_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out)
+{
+    if (n == 0) { HIP_TRY(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return IPKGPU_OK; }
+    const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (nb > 0x7fffffffull) return fail(ctx, IPKGPU_ERR_INVALID, "scan too large");
+    RC_TRY(ensure(ctx, ctx->scan_sums, nb * 4));
+    RC_TRY(ensure(ctx, ctx->scan_boff, (nb + 1) * 8));
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((uint32_t)nb), dim3(256), 0, ctx->stream, in, n, ctx->scan_sums.as<uint32_t>());
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->scan_sums.as<uint32_t>(), nb, (uint64_t)0,
+                       ctx->scan_boff.as<uint64_t>());
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((uint32_t)nb), dim3(256), 0, ctx->stream, in, n, ctx->scan_boff.as<uint64_t>(), out);
+    HIP_TRY(ctx, hipGetLastError());
+    return IPKGPU_OK;
+}
 
 }  // namespace
 
 extern "C" {
 
+// ---- group-major output ------------------------------------------------------------------------------
 int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t n_mats, uint32_t sites,
                                uint32_t sigma, const uint32_t* mat_group, uint32_t k, float log_eps,
                                ipkgpu_result** out)
@@ -549,175 +435,86 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
     if (!ctx) return IPKGPU_ERR_INVALID;
     if (!out) return fail(ctx, IPKGPU_ERR_INVALID, "null out pointer");
     *out = nullptr;
-    if (!logp_dev || !mat_group) return fail(ctx, IPKGPU_ERR_INVALID, "null input pointer");
-    if (sigma != 4 && sigma != 20) return fail(ctx, IPKGPU_ERR_INVALID, "unsupported alphabet size %u (4 or 20)", sigma);
-    if (k < 2 || k > ipkgpu_max_k(sigma))
-        return fail(ctx, IPKGPU_ERR_INVALID, "k=%u out of range [2, %u] for sigma=%u", k, ipkgpu_max_k(sigma), sigma);
-    if (n_mats == 0) return fail(ctx, IPKGPU_ERR_INVALID, "no matrices");
-    if (sites < k) return fail(ctx, IPKGPU_ERR_INVALID, "alignment has %u sites, fewer than k=%u", sites, k);
+    Plan pl;
+    RC_TRY(make_plan(ctx, logp_dev, n_mats, sites, sigma, mat_group, k, log_eps, pl));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-
-    // group discovery: first-seen order of branch ids (group_ghost_ids, db_builder.cpp:524-553)
-    std::vector<uint32_t> group_ids;
-    std::vector<uint32_t> slot_of(n_mats);
-    {
-        std::unordered_map<uint32_t, uint32_t> index;
-        index.reserve(n_mats);
-        for (uint32_t i = 0; i < n_mats; ++i) {
-            auto it = index.find(mat_group[i]);
-            if (it == index.end()) {
-                it = index.emplace(mat_group[i], (uint32_t)group_ids.size()).first;
-                group_ids.push_back(mat_group[i]);
-            }
-            slot_of[i] = it->second;
-        }
-    }
-    const uint32_t n_groups = (uint32_t)group_ids.size();
-    const uint64_t table_size = ipow(sigma, (int)k);
-    const uint64_t table_bytes = table_size * 4;
-    uint64_t gpb = std::max<uint64_t>(1, (uint64_t)ctx->workspace_bytes / table_bytes);
-    gpb = std::min<uint64_t>(gpb, n_groups);
-    const uint32_t chunks_per_group = (uint32_t)((table_size + CHUNK - 1) / CHUNK);
-    while (gpb > 1 && gpb * chunks_per_group > 0x7fffffffull) gpb /= 2;
-    const uint32_t nwin = sites - k + 1;
-    const uint32_t tiles_per_mat = (nwin + TW - 1) / TW;
+    const uint32_t n_groups = pl.n_groups, cpg = pl.chunks_per_group;
 
     ipkgpu_result* res = new (std::nothrow) ipkgpu_result();
     if (!res) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
     res->ctx = ctx;
-    res->group_ids = group_ids;
+    res->group_ids = pl.group_ids;
     res->offsets.assign((size_t)n_groups + 1, 0);
-    auto bail = [&](int rc) { ipkgpu_result_free(res); return rc; };
-#define TRY_RC(expr) do { int rc_ = (expr); if (rc_) return bail(rc_); } while (0)
-#define HIP_TRY_R(expr)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return bail(fail(ctx, e_ == hipErrorOutOfMemory ? IPKGPU_ERR_NOMEM : IPKGPU_ERR_HIP, \
-                             "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__)); \
-    } while (0)
+    struct Guard { ipkgpu_result* r; ~Guard() { if (r) ipkgpu_result_free(r); } } guard{res};
 
-    TRY_RC(ensure(ctx, &ctx->best, &ctx->best_cap, (size_t)n_mats * (sites + 1) * 4));
-    TRY_RC(ensure(ctx, &ctx->table, &ctx->table_cap, (size_t)(gpb * table_bytes)));
-    TRY_RC(ensure(ctx, &ctx->idx, &ctx->idx_cap, (size_t)n_mats * 8));
-    TRY_RC(ensure(ctx, &ctx->counts, &ctx->counts_cap, (size_t)(gpb * chunks_per_group) * 4));
-    TRY_RC(ensure(ctx, &ctx->offsets, &ctx->offsets_cap, (size_t)(gpb * chunks_per_group + 1) * 8));
-    TRY_RC(ensure(ctx, &ctx->goff, &ctx->goff_cap, (size_t)(gpb + 1) * 8));
+    RC_TRY(ensure(ctx, ctx->counts, (size_t)(pl.gpb * cpg) * 4));
+    RC_TRY(ensure(ctx, ctx->offsets, (size_t)(pl.gpb * cpg + 1) * 8));
+    RC_TRY(ensure(ctx, ctx->goff, (size_t)(pl.gpb + 1) * 8));
 
-    std::vector<hipEvent_t> events;
-    auto new_event = [&]() { hipEvent_t e = nullptr; hipEventCreate(&e); events.push_back(e); return e; };
-    auto record = [&](hipEvent_t e) { return hipEventRecord(e, ctx->stream); };
-    hipEvent_t ev_begin = new_event(), ev_pre = new_event(), ev_end = new_event();
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_score, ev_compact;
-
-    unsigned long long* d_emitted = reinterpret_cast<unsigned long long*>(ctx->small);
-    uint32_t* d_ovf_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 16);
-    HIP_TRY_R(hipMemsetAsync(ctx->small, 0, 64, ctx->stream));
-
-    HIP_TRY_R(record(ev_begin));
-    if (sigma == 4)
-        hipLaunchKernelGGL(prefix_max_kernel<4>, dim3(n_mats), dim3(256), 0, ctx->stream, logp_dev, sites, (float*)ctx->best);
-    else
-        hipLaunchKernelGGL(prefix_max_kernel<20>, dim3(n_mats), dim3(256), 0, ctx->stream, logp_dev, sites, (float*)ctx->best);
-    HIP_TRY_R(hipGetLastError());
-    HIP_TRY_R(record(ev_pre));
-
-    // batches of groups whose tables fit the workspace
-    std::vector<uint32_t> idx_host((size_t)n_mats * 2);
+    Stopwatch sw(ctx->stream);
+    const int t_begin = sw.mark();
+    RC_TRY(run_prefix(ctx, pl, logp_dev));
+    const int t_pre = sw.mark();
+    std::vector<std::pair<int, int>> ev_score, ev_compact;
+    std::vector<uint32_t> idx_host;
     uint64_t total_entries = 0;
-    for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)gpb) {
-        const uint32_t gb = std::min<uint32_t>((uint32_t)gpb, n_groups - g0);
-        uint32_t nb = 0;
-        uint32_t* mat_list_h = idx_host.data();
-        uint32_t* mat_slot_h = idx_host.data() + n_mats;
-        for (uint32_t i = 0; i < n_mats; ++i) {
-            mat_slot_h[i] = 0;
-            if (slot_of[i] >= g0 && slot_of[i] < g0 + gb) { mat_list_h[nb++] = i; mat_slot_h[i] = slot_of[i] - g0; }
-        }
-        HIP_TRY_R(hipMemcpyAsync(ctx->idx, idx_host.data(), (size_t)n_mats * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY_R(hipStreamSynchronize(ctx->stream));     // idx_host is reused by the next batch
-        TRY_RC(ensure(ctx, &ctx->ovfq, &ctx->ovfq_cap, (size_t)nb * nwin * 8));
-
-        ScoreParams p;
-        p.logp = logp_dev;
-        p.best = (const float*)ctx->best;
-        p.mat_list = (const uint32_t*)ctx->idx;
-        p.mat_slot = (const uint32_t*)ctx->idx + n_mats;
-        p.n_batch_mats = nb; p.sites = sites; p.nwin = nwin; p.tiles_per_mat = tiles_per_mat;
-        p.eps = log_eps;
-        p.table = (uint32_t*)ctx->table;
-        p.table_size = table_size;
-        p.emitted = d_emitted;
-        p.ovf_queue = (unsigned long long*)ctx->ovfq;
-        p.ovf_count = d_ovf_count;
-        p.flags = (uint32_t)(ctx->opt_variant == 99 ? 1 : 0);
-
-        hipEvent_t s0 = new_event(), s1 = new_event(), c1 = new_event();
-        HIP_TRY_R(hipMemsetAsync(ctx->table, 0, (size_t)gb * table_bytes, ctx->stream));
-        HIP_TRY_R(hipMemsetAsync(d_ovf_count, 0, 4, ctx->stream));
-        HIP_TRY_R(record(s0));
-        TRY_RC(dispatch_score(ctx, sigma, k, p));
-        HIP_TRY_R(record(s1));
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)pl.gpb) {
+        const uint32_t gb = std::min<uint32_t>((uint32_t)pl.gpb, n_groups - g0);
+        const int s0 = sw.mark();
+        RC_TRY(score_batch(ctx, pl, logp_dev, g0, gb, idx_host));
+        const int s1 = sw.mark();
         ev_score.push_back({s0, s1});
         res->score_launches += 1;
 
-        const uint32_t n_chunks = gb * chunks_per_group;
+        const uint32_t n_chunks = gb * cpg;
         hipLaunchKernelGGL(count_chunks_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream,
-                           (const uint32_t*)ctx->table, table_size, chunks_per_group, (uint32_t*)ctx->counts);
-        HIP_TRY_R(hipGetLastError());
+                           ctx->table.as<uint32_t>(), pl.table_size, cpg, ctx->counts.as<uint32_t>());
         hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                           (const uint32_t*)ctx->counts, (uint64_t)n_chunks, total_entries, (uint64_t*)ctx->offsets);
-        HIP_TRY_R(hipGetLastError());
-        // group offsets of this batch (every chunks_per_group-th offset) + new total
-        std::vector<uint64_t> goff((size_t)gb + 1);
+                           ctx->counts.as<uint32_t>(), (uint64_t)n_chunks, total_entries, ctx->offsets.as<uint64_t>());
         hipLaunchKernelGGL(gather_offsets_kernel, dim3((gb + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                           (const uint64_t*)ctx->offsets, chunks_per_group, gb + 1, (uint64_t*)ctx->goff);
-        HIP_TRY_R(hipGetLastError());
-        HIP_TRY_R(hipMemcpyAsync(goff.data(), ctx->goff, ((size_t)gb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY_R(hipStreamSynchronize(ctx->stream));
+                           ctx->offsets.as<uint64_t>(), cpg, gb + 1, ctx->goff.as<uint64_t>());
+        HIP_TRY(ctx, hipGetLastError());
+        std::vector<uint64_t> goff((size_t)gb + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(goff.data(), ctx->goff.p, ((size_t)gb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         for (uint32_t g = 0; g <= gb; ++g) res->offsets[g0 + g] = goff[g];
         const uint64_t new_total = goff[gb];
         if (new_total > res->cap) {
-            // grow the output (exact for a single batch; doubling across batches)
+            // grow the output (exact when the last batch is reached; doubling across batches)
             const size_t new_cap = (g0 + gb >= n_groups) ? (size_t)new_total : (size_t)std::max<uint64_t>(new_total, 2 * res->cap);
             uint32_t* nk = nullptr; float* ns = nullptr;
-            HIP_TRY_R(hipMalloc((void**)&nk, std::max<size_t>(new_cap, 1) * 4));
+            HIP_TRY(ctx, hipMalloc((void**)&nk, std::max<size_t>(new_cap, 1) * 4));
             hipError_t e2 = hipMalloc((void**)&ns, std::max<size_t>(new_cap, 1) * 4);
-            if (e2 != hipSuccess) { hipFree(nk); HIP_TRY_R(e2); }
+            if (e2 != hipSuccess) { (void)hipFree(nk); HIP_TRY(ctx, e2); }
             if (total_entries) {
-                hipMemcpyAsync(nk, res->d_keys, total_entries * 4, hipMemcpyDeviceToDevice, ctx->stream);
-                hipMemcpyAsync(ns, res->d_scores, total_entries * 4, hipMemcpyDeviceToDevice, ctx->stream);
-                hipStreamSynchronize(ctx->stream);
+                (void)hipMemcpyAsync(nk, res->d_keys, total_entries * 4, hipMemcpyDeviceToDevice, ctx->stream);
+                (void)hipMemcpyAsync(ns, res->d_scores, total_entries * 4, hipMemcpyDeviceToDevice, ctx->stream);
+                (void)hipStreamSynchronize(ctx->stream);
             }
-            if (res->d_keys) hipFree(res->d_keys);
-            if (res->d_scores) hipFree(res->d_scores);
+            if (res->d_keys) (void)hipFree(res->d_keys);
+            if (res->d_scores) (void)hipFree(res->d_scores);
             res->d_keys = nk; res->d_scores = ns; res->cap = new_cap;
         }
         if (sigma == 4)
-            hipLaunchKernelGGL(write_chunks_kernel<4>, dim3(n_chunks), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->table,
-                               table_size, chunks_per_group, (int)k, (const uint64_t*)ctx->offsets, res->d_keys, res->d_scores);
+            hipLaunchKernelGGL(write_chunks_kernel<4>, dim3(n_chunks), dim3(256), 0, ctx->stream, ctx->table.as<uint32_t>(),
+                               pl.table_size, cpg, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);
         else
-            hipLaunchKernelGGL(write_chunks_kernel<20>, dim3(n_chunks), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->table,
-                               table_size, chunks_per_group, (int)k, (const uint64_t*)ctx->offsets, res->d_keys, res->d_scores);
-        HIP_TRY_R(hipGetLastError());
-        HIP_TRY_R(record(c1));
-        ev_compact.push_back({s1, c1});
+            hipLaunchKernelGGL(write_chunks_kernel<20>, dim3(n_chunks), dim3(256), 0, ctx->stream, ctx->table.as<uint32_t>(),
+                               pl.table_size, cpg, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);
+        HIP_TRY(ctx, hipGetLastError());
+        ev_compact.push_back({s1, sw.mark()});
         total_entries = new_total;
     }
-    HIP_TRY_R(record(ev_end));
+    const int t_end = sw.mark();
     unsigned long long emitted = 0;
-    HIP_TRY_R(hipMemcpyAsync(&emitted, d_emitted, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY_R(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&emitted, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     res->emitted = emitted;
-
-    float ms = 0;
-    hipEventElapsedTime(&ms, ev_begin, ev_end); res->t_total = ms;
-    hipEventElapsedTime(&ms, ev_begin, ev_pre); res->t_prefix = ms;
-    for (auto& pr : ev_score) { hipEventElapsedTime(&ms, pr.first, pr.second); res->t_score += ms; }
-    for (auto& pr : ev_compact) { hipEventElapsedTime(&ms, pr.first, pr.second); res->t_compact += ms; }
-    for (hipEvent_t e : events) hipEventDestroy(e);
-#undef TRY_RC
-#undef HIP_TRY_R
+    res->t_total = sw.ms(t_begin, t_end);
+    res->t_prefix = sw.ms(t_begin, t_pre);
+    for (auto& pr : ev_score) res->t_score += sw.ms(pr.first, pr.second);
+    for (auto& pr : ev_compact) res->t_compact += sw.ms(pr.first, pr.second);
+    guard.r = nullptr;
     *out = res;
     return IPKGPU_OK;
 }
@@ -736,9 +533,9 @@ int ipkgpu_score_groups(ipkgpu_ctx* ctx, const float* logp, uint32_t n_mats, uin
     float* d = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d, std::max<size_t>(bytes, 4)));
     hipError_t e = hipMemcpy(d, logp, bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(d); HIP_TRY(ctx, e); }
+    if (e != hipSuccess) { (void)hipFree(d); HIP_TRY(ctx, e); }
     const int rc = ipkgpu_score_groups_device(ctx, d, n_mats, sites, sigma, mat_group, k, log_eps, out);
-    hipFree(d);
+    (void)hipFree(d);
     return rc;
 }
 
@@ -755,7 +552,7 @@ const uint32_t* ipkgpu_result_keys(ipkgpu_result* r)
     if (!r->h_keys_ok) {
         const size_t n = (size_t)r->offsets.back();
         r->h_keys.resize(std::max<size_t>(n, 1));
-        hipSetDevice(r->ctx->device);
+        (void)hipSetDevice(r->ctx->device);
         if (n && hipMemcpy(r->h_keys.data(), r->d_keys, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
         r->h_keys_ok = true;
     }
@@ -768,7 +565,7 @@ const float* ipkgpu_result_scores(ipkgpu_result* r)
     if (!r->h_scores_ok) {
         const size_t n = (size_t)r->offsets.back();
         r->h_scores.resize(std::max<size_t>(n, 1));
-        hipSetDevice(r->ctx->device);
+        (void)hipSetDevice(r->ctx->device);
         if (n && hipMemcpy(r->h_scores.data(), r->d_scores, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
         r->h_scores_ok = true;
     }
@@ -791,10 +588,298 @@ double ipkgpu_result_time_ms(const ipkgpu_result* r, int which)
 void ipkgpu_result_free(ipkgpu_result* r)
 {
     if (!r) return;
-    if (r->ctx) hipSetDevice(r->ctx->device);
-    if (r->d_keys) hipFree(r->d_keys);
-    if (r->d_scores) hipFree(r->d_scores);
+    if (r->ctx) (void)hipSetDevice(r->ctx->device);
+    if (r->d_keys) (void)hipFree(r->d_keys);
+    if (r->d_scores) (void)hipFree(r->d_scores);
     delete r;
+}
+
+}  // extern "C"
+
+// ---- key-major output: database parts and their merge ----------------------------------------------
+namespace {
+
+// Merges S sources of one owner: counts [S][slots] (contiguous), entries of source s start at
+// src + src_base[s].  Writes dst entries (n_total), dst_off [slots+1] into ctx->tmp_b, and, when
+// `db` is given, the compact key list.
+int merge_sources(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, uint32_t P, uint32_t S, uint64_t slots,
+                  const uint32_t* counts, const uint2* src, const std::vector<uint64_t>& src_base,
+                  uint32_t* total_out /*[slots] device*/, uint2** dst_out, uint64_t* n_total_out, ipkgpu_db* db)
+{
+    // workspaces: tmp_a = flags u32[slots] ; tmp_b = dst_off u64[slots+1] ; tmp_c = src_off u64[S][slots+1]
+    RC_TRY(ensure(ctx, ctx->tmp_a, slots * 4));
+    RC_TRY(ensure(ctx, ctx->tmp_b, (slots + 1) * 8));
+    RC_TRY(ensure(ctx, ctx->tmp_c, (size_t)S * (slots + 1) * 8));
+    const uint32_t nb256 = (uint32_t)((slots + 255) / 256);
+    hipLaunchKernelGGL(merge_sum_counts_kernel, dim3(nb256), dim3(256), 0, ctx->stream, counts, S, slots, total_out,
+                       ctx->tmp_a.as<uint32_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    RC_TRY(scan_u32(ctx, total_out, slots, ctx->tmp_b.as<uint64_t>()));
+    for (uint32_t s = 0; s < S; ++s)
+        RC_TRY(scan_u32(ctx, counts + (size_t)s * slots, slots, ctx->tmp_c.as<uint64_t>() + (size_t)s * (slots + 1)));
+    uint64_t n_total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_total, ctx->tmp_b.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // per-source scans are relative to the source's own start: add the bases on the host side by
+    // passing adjusted source pointers is not possible for one `src`, so fold the base into the scan
+    // output with a tiny kernel-free trick: the copy kernel takes src_off relative to `src`; we add
+    // src_base[s] to source s's whole offset row here.
+    for (uint32_t s = 0; s < S; ++s) {
+        if (src_base[s] == 0) continue;
+        hipLaunchKernelGGL(add_base_kernel, dim3((uint32_t)((slots + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->tmp_c.as<uint64_t>() + (size_t)s * (slots + 1), slots + 1, src_base[s]);
+    }
+    uint2* dst = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&dst, std::max<uint64_t>(n_total, 1) * 8));
+    if (slots) {
+        hipLaunchKernelGGL(merge_copy_kernel, dim3((uint32_t)((slots + 3) / 4)), dim3(256), 0, ctx->stream, counts, S, slots,
+                           ctx->tmp_c.as<uint64_t>(), src, ctx->tmp_b.as<uint64_t>(), dst);
+    }
+    *dst_out = dst;                       // owned by the caller from here on (also on failure)
+    *n_total_out = n_total;
+    HIP_TRY(ctx, hipGetLastError());
+    if (db) {
+        // compact key list: scan of flags (reuses tmp_c as flag offsets: the copy kernel is stream-ordered before)
+        RC_TRY(ensure(ctx, ctx->offsets, (slots + 1) * 8));
+        RC_TRY(scan_u32(ctx, ctx->tmp_a.as<uint32_t>(), slots, ctx->offsets.as<uint64_t>()));
+        uint64_t n_keys = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&n_keys, ctx->offsets.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMalloc((void**)&db->d_keys, std::max<uint64_t>(n_keys, 1) * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&db->d_key_off, (n_keys + 1) * 8));
+        const uint32_t nbk = (uint32_t)((slots + 1 + 255) / 256);
+        if (sigma == 4)
+            hipLaunchKernelGGL(merge_write_keys_kernel<4>, dim3(nbk), dim3(256), 0, ctx->stream, total_out, ctx->offsets.as<uint64_t>(),
+                               ctx->tmp_b.as<uint64_t>(), slots, owner, P, (int)k, db->d_keys, db->d_key_off);
+        else
+            hipLaunchKernelGGL(merge_write_keys_kernel<20>, dim3(nbk), dim3(256), 0, ctx->stream, total_out, ctx->offsets.as<uint64_t>(),
+                               ctx->tmp_b.as<uint64_t>(), slots, owner, P, (int)k, db->d_keys, db->d_key_off);
+        HIP_TRY(ctx, hipGetLastError());
+        db->n_keys = n_keys;
+    }
+    return IPKGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t n_mats, uint32_t sites,
+                                        uint32_t sigma, const uint32_t* mat_group, uint32_t k, float log_eps,
+                                        uint32_t n_owners, ipkgpu_parts** out)
+{
+    if (!ctx) return IPKGPU_ERR_INVALID;
+    if (!out) return fail(ctx, IPKGPU_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (n_owners == 0) return fail(ctx, IPKGPU_ERR_INVALID, "n_owners must be >= 1");
+    Plan pl;
+    RC_TRY(make_plan(ctx, logp_dev, n_mats, sites, sigma, mat_group, k, log_eps, pl));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t T = pl.table_size;
+    const uint32_t P = n_owners;
+    const uint64_t slots = (T + P - 1) / P;
+    const uint32_t n_groups = pl.n_groups;
+
+    ipkgpu_parts* parts = new (std::nothrow) ipkgpu_parts();
+    if (!parts) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
+    parts->ctx = ctx; parts->n_owners = P; parts->slots = slots;
+    parts->owner_off.assign((size_t)P + 1, 0);
+    struct Guard { ipkgpu_parts* r; ~Guard() { if (r) ipkgpu_parts_free(r); } } guard{parts};
+
+    RC_TRY(ensure(ctx, ctx->branch, (size_t)n_groups * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->branch.p, pl.group_ids.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    Stopwatch sw(ctx->stream);
+    const int t_begin = sw.mark();
+    RC_TRY(run_prefix(ctx, pl, logp_dev));
+    const int t_pre = sw.mark();
+    std::vector<std::pair<int, int>> ev_score, ev_compact;
+    std::vector<uint32_t> idx_host;
+
+    struct Batch { uint32_t* counts = nullptr; uint2* entries = nullptr; std::vector<uint64_t> owner_off; };
+    std::vector<Batch> batches;
+    auto free_batches = [&]() { for (auto& b : batches) { if (b.counts) (void)hipFree(b.counts); if (b.entries) (void)hipFree(b.entries); } batches.clear(); };
+    struct BGuard { decltype(free_batches)& f; ~BGuard() { f(); } } bguard{free_batches};
+
+    const uint64_t n_slots_all = (uint64_t)P * slots;
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)pl.gpb) {
+        const uint32_t gb = std::min<uint32_t>((uint32_t)pl.gpb, n_groups - g0);
+        const int s0 = sw.mark();
+        RC_TRY(score_batch(ctx, pl, logp_dev, g0, gb, idx_host));
+        const int s1 = sw.mark();
+        ev_score.push_back({s0, s1});
+        parts->score_launches += 1;
+
+        batches.emplace_back();
+        Batch& b = batches.back();
+        HIP_TRY(ctx, hipMalloc((void**)&b.counts, n_slots_all * 4));
+        HIP_TRY(ctx, hipMemsetAsync(b.counts, 0, n_slots_all * 4, ctx->stream));
+        hipLaunchKernelGGL(km_count_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->table.as<uint32_t>(), T, gb, P, slots, b.counts);
+        HIP_TRY(ctx, hipGetLastError());
+        RC_TRY(ensure(ctx, ctx->offsets, (n_slots_all + 1) * 8));
+        RC_TRY(scan_u32(ctx, b.counts, n_slots_all, ctx->offsets.as<uint64_t>()));
+        // owner offsets of this batch
+        RC_TRY(ensure(ctx, ctx->goff, ((size_t)P + 1) * 8));
+        hipLaunchKernelGGL(gather_offsets_kernel, dim3((P + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                           ctx->offsets.as<uint64_t>(), (uint32_t)slots, P + 1, ctx->goff.as<uint64_t>());
+        HIP_TRY(ctx, hipGetLastError());
+        b.owner_off.resize((size_t)P + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(b.owner_off.data(), ctx->goff.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMalloc((void**)&b.entries, std::max<uint64_t>(b.owner_off[P], 1) * 8));
+        hipLaunchKernelGGL(km_write_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
+                           ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
+                           ctx->offsets.as<uint64_t>(), b.entries);
+        HIP_TRY(ctx, hipGetLastError());
+        ev_compact.push_back({s1, sw.mark()});
+    }
+
+    if (batches.size() == 1) {
+        parts->d_counts = batches[0].counts; parts->d_entries = batches[0].entries;
+        parts->owner_off = batches[0].owner_off;
+        batches[0].counts = nullptr; batches[0].entries = nullptr;
+    } else {
+        // several batches of groups: per owner, merge the batches (sources in batch = group order)
+        const int m0 = sw.mark();
+        const uint32_t S = (uint32_t)batches.size();
+        HIP_TRY(ctx, hipMalloc((void**)&parts->d_counts, n_slots_all * 4));
+        uint64_t grand = 0;
+        for (auto& b : batches) grand += b.owner_off[P];
+        HIP_TRY(ctx, hipMalloc((void**)&parts->d_entries, std::max<uint64_t>(grand, 1) * 8));
+        uint32_t* cnt_rows = nullptr;      // [S][slots] of the current owner
+        HIP_TRY(ctx, hipMalloc((void**)&cnt_rows, (size_t)S * slots * 4));
+        uint2* src_cat = nullptr;          // sources of the current owner, concatenated
+        uint64_t done = 0;
+        int rc = IPKGPU_OK;
+        for (uint32_t o = 0; o < P && rc == IPKGPU_OK; ++o) {
+            std::vector<uint64_t> base(S);
+            uint64_t n_o = 0;
+            for (uint32_t s = 0; s < S; ++s) { base[s] = n_o; n_o += batches[s].owner_off[o + 1] - batches[s].owner_off[o]; }
+            if (hipMalloc((void**)&src_cat, std::max<uint64_t>(n_o, 1) * 8) != hipSuccess) { rc = fail(ctx, IPKGPU_ERR_NOMEM, "out of device memory in batch merge"); break; }
+            for (uint32_t s = 0; s < S; ++s) {
+                (void)hipMemcpyAsync(cnt_rows + (size_t)s * slots, batches[s].counts + (size_t)o * slots, slots * 4, hipMemcpyDeviceToDevice, ctx->stream);
+                const uint64_t n_s = batches[s].owner_off[o + 1] - batches[s].owner_off[o];
+                if (n_s) (void)hipMemcpyAsync(src_cat + base[s], batches[s].entries + batches[s].owner_off[o], n_s * 8, hipMemcpyDeviceToDevice, ctx->stream);
+            }
+            uint2* dst = nullptr; uint64_t n_total = 0;
+            rc = merge_sources(ctx, sigma, k, o, P, S, slots, cnt_rows, src_cat, base, parts->d_counts + (size_t)o * slots, &dst, &n_total, nullptr);
+            if (rc == IPKGPU_OK) {
+                if (n_total) (void)hipMemcpyAsync(parts->d_entries + done, dst, n_total * 8, hipMemcpyDeviceToDevice, ctx->stream);
+                (void)hipStreamSynchronize(ctx->stream);
+                parts->owner_off[o] = done; done += n_total; parts->owner_off[o + 1] = done;
+            }
+            if (dst) (void)hipFree(dst);
+            (void)hipFree(src_cat); src_cat = nullptr;
+        }
+        (void)hipFree(cnt_rows);
+        if (rc) return rc;
+        ev_compact.push_back({m0, sw.mark()});
+    }
+    const int t_end = sw.mark();
+    unsigned long long emitted = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&emitted, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    parts->emitted = emitted;
+    parts->t_total = sw.ms(t_begin, t_end);
+    parts->t_prefix = sw.ms(t_begin, t_pre);
+    for (auto& pr : ev_score) parts->t_score += sw.ms(pr.first, pr.second);
+    for (auto& pr : ev_compact) parts->t_compact += sw.ms(pr.first, pr.second);
+    guard.r = nullptr;
+    *out = parts;
+    return IPKGPU_OK;
+}
+
+uint32_t ipkgpu_parts_num_owners(const ipkgpu_parts* p) { return p ? p->n_owners : 0; }
+uint64_t ipkgpu_parts_slots(const ipkgpu_parts* p) { return p ? p->slots : 0; }
+const uint32_t* ipkgpu_parts_counts_device(const ipkgpu_parts* p) { return p ? p->d_counts : nullptr; }
+const void* ipkgpu_parts_entries_device(const ipkgpu_parts* p) { return p ? p->d_entries : nullptr; }
+const uint64_t* ipkgpu_parts_owner_offsets(const ipkgpu_parts* p) { return p ? p->owner_off.data() : nullptr; }
+uint64_t ipkgpu_parts_emitted(const ipkgpu_parts* p) { return p ? p->emitted : 0; }
+double ipkgpu_parts_time_ms(const ipkgpu_parts* p, int which)
+{
+    if (!p) return 0;
+    switch (which) {
+        case IPKGPU_T_TOTAL: return p->t_total;
+        case IPKGPU_T_PREFIX: return p->t_prefix;
+        case IPKGPU_T_SCORE: return p->t_score;
+        case IPKGPU_T_COMPACT: return p->t_compact;
+        case IPKGPU_T_SCORE_LAUNCHES: return (double)p->score_launches;
+    }
+    return 0;
+}
+void ipkgpu_parts_free(ipkgpu_parts* p)
+{
+    if (!p) return;
+    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    if (p->d_counts) (void)hipFree(p->d_counts);
+    if (p->d_entries) (void)hipFree(p->d_entries);
+    delete p;
+}
+
+int ipkgpu_merge_parts(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, uint32_t n_owners, uint32_t n_sources,
+                       const uint32_t* counts_dev, const void* entries_dev, const uint64_t* source_offsets, ipkgpu_db** out)
+{
+    if (!ctx) return IPKGPU_ERR_INVALID;
+    if (!out) return fail(ctx, IPKGPU_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!counts_dev || !source_offsets) return fail(ctx, IPKGPU_ERR_INVALID, "null input pointer");
+    if ((sigma != 4 && sigma != 20) || k < 2 || k > ipkgpu_max_k(sigma)) return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+    if (n_owners == 0 || owner >= n_owners || n_sources == 0) return fail(ctx, IPKGPU_ERR_INVALID, "bad owner/source counts");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t T = ipow(sigma, (int)k);
+    const uint64_t slots = (T + n_owners - 1) / n_owners;
+    ipkgpu_db* db = new (std::nothrow) ipkgpu_db();
+    if (!db) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
+    db->ctx = ctx;
+    struct Guard { ipkgpu_db* r; ~Guard() { if (r) ipkgpu_db_free(r); } } guard{db};
+    Stopwatch sw(ctx->stream);
+    const int t0 = sw.mark();
+    std::vector<uint64_t> base(source_offsets, source_offsets + n_sources);
+    RC_TRY(ensure(ctx, ctx->counts, slots * 4));
+    RC_TRY(merge_sources(ctx, sigma, k, owner, n_owners, n_sources, slots, counts_dev, reinterpret_cast<const uint2*>(entries_dev),
+                         base, ctx->counts.as<uint32_t>(), &db->d_entries, &db->n_entries, db));
+    const int t1 = sw.mark();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    db->t_merge = sw.ms(t0, t1);
+    guard.r = nullptr;
+    *out = db;
+    return IPKGPU_OK;
+}
+
+uint64_t ipkgpu_db_num_keys(const ipkgpu_db* d) { return d ? d->n_keys : 0; }
+uint64_t ipkgpu_db_num_entries(const ipkgpu_db* d) { return d ? d->n_entries : 0; }
+const uint32_t* ipkgpu_db_keys_device(const ipkgpu_db* d) { return d ? d->d_keys : nullptr; }
+const uint64_t* ipkgpu_db_key_offsets_device(const ipkgpu_db* d) { return d ? d->d_key_off : nullptr; }
+const void* ipkgpu_db_entries_device(const ipkgpu_db* d) { return d ? d->d_entries : nullptr; }
+double ipkgpu_db_time_ms(const ipkgpu_db* d) { return d ? d->t_merge : 0; }
+
+static bool db_to_host(ipkgpu_db* d)
+{
+    if (d->h_ok) return true;
+    (void)hipSetDevice(d->ctx->device);
+    d->h_keys.resize(std::max<uint64_t>(d->n_keys, 1));
+    d->h_key_off.resize(d->n_keys + 1);
+    d->h_entries.resize(std::max<uint64_t>(d->n_entries, 1) * 2);
+    if (d->n_keys && hipMemcpy(d->h_keys.data(), d->d_keys, d->n_keys * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(d->h_key_off.data(), d->d_key_off, (d->n_keys + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (d->n_entries && hipMemcpy(d->h_entries.data(), d->d_entries, d->n_entries * 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    d->h_ok = true;
+    return true;
+}
+const uint32_t* ipkgpu_db_keys(ipkgpu_db* d) { return d && db_to_host(d) ? d->h_keys.data() : nullptr; }
+const uint64_t* ipkgpu_db_key_offsets(ipkgpu_db* d) { return d && db_to_host(d) ? d->h_key_off.data() : nullptr; }
+const uint32_t* ipkgpu_db_entries(ipkgpu_db* d) { return d && db_to_host(d) ? d->h_entries.data() : nullptr; }
+
+void ipkgpu_db_free(ipkgpu_db* d)
+{
+    if (!d) return;
+    if (d->ctx) (void)hipSetDevice(d->ctx->device);
+    if (d->d_keys) (void)hipFree(d->d_keys);
+    if (d->d_key_off) (void)hipFree(d->d_key_off);
+    if (d->d_entries) (void)hipFree(d->d_entries);
+    delete d;
 }
 
 }  // extern "C"

@@ -1,0 +1,105 @@
+// kernels_compact.hpp -- dense per-group tables -> group-major CSR (sorted keys per branch group).
+#pragma once
+#include "dcla_device.hpp"
+
+namespace ipkgpu {
+
+// ---- table -> CSR compaction -------------------------------------------------------------------
+constexpr uint32_t CHUNK = 4096;   // table slots per workgroup
+
+__global__ __launch_bounds__(256) void count_chunks_kernel(const uint32_t* __restrict__ table, uint64_t table_size,
+                                                           uint32_t chunks_per_group, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t g = blockIdx.x / chunks_per_group, c = blockIdx.x - g * chunks_per_group;
+    const uint32_t* t = table + (size_t)g * table_size;
+    const uint64_t s0 = (uint64_t)c * CHUNK;
+    const uint32_t n = (uint32_t)min((uint64_t)CHUNK, table_size - s0);
+    uint32_t cnt = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) cnt += (t[s0 + i] != 0u);
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Exclusive scan of n u32 counts into n+1 u64 offsets (single workgroup; n is ~1e5..1e7).
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __restrict__ counts, uint64_t n,
+                                                           uint64_t base, uint64_t* __restrict__ offsets)
+{
+    __shared__ uint64_t part[1024];
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t lo = min(n, (uint64_t)threadIdx.x * per), hi = min(n, lo + per);
+    uint64_t s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t acc = base;
+        for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = acc; acc += v; }
+        offsets[n] = acc;
+    }
+    __syncthreads();
+    uint64_t acc = part[threadIdx.x];
+    for (uint64_t i = lo; i < hi; ++i) { offsets[i] = acc; acc += counts[i]; }
+}
+
+// offsets[g * stride] for g in [0, n) -> out[g]: the per-group CSR offsets of a batch
+__global__ void gather_offsets_kernel(const uint64_t* __restrict__ offsets, uint32_t stride, uint32_t n,
+                                      uint64_t* __restrict__ out)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) out[g] = offsets[(size_t)g * stride];
+}
+
+template <int SIGMA>
+__device__ __forceinline__ uint32_t pack_code(uint32_t dense, int k)
+{
+    if constexpr (SIGMA == 4) { (void)k; return dense; }
+    else {
+        constexpr int BITS = 5;
+        uint32_t key = 0;
+        for (int d = 0; d < k; ++d) {                 // last symbol in the lowest bits
+            const uint32_t q = dense / SIGMA;
+            key |= (dense - q * SIGMA) << (BITS * d);
+            dense = q;
+        }
+        return key;
+    }
+}
+
+template <int SIGMA>
+__global__ __launch_bounds__(256) void write_chunks_kernel(const uint32_t* __restrict__ table, uint64_t table_size,
+                                                           uint32_t chunks_per_group, int k,
+                                                           const uint64_t* __restrict__ offsets,
+                                                           uint32_t* __restrict__ keys, float* __restrict__ scores)
+{
+    __shared__ uint32_t wcnt[4];
+    const uint32_t g = blockIdx.x / chunks_per_group, c = blockIdx.x - g * chunks_per_group;
+    const uint32_t* t = table + (size_t)g * table_size;
+    const uint64_t s0 = (uint64_t)c * CHUNK;
+    const uint32_t n = (uint32_t)min((uint64_t)CHUNK, table_size - s0);
+    uint64_t out = offsets[blockIdx.x];
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t v = 0;
+        if (i < n) v = t[s0 + i];
+        const uint64_t m = __ballot(v != 0u);
+        if (lane_id() == 0) wcnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) { const uint32_t x = wcnt[q]; total += x; if (q < wave) before += x; }
+        if (v != 0u) {
+            const uint64_t pos = out + before + mbcnt(m);
+            keys[pos] = pack_code<SIGMA>((uint32_t)(s0 + i), k);
+            scores[pos] = __uint_as_float(dec_score_bits(v));
+        }
+        out += total;
+        __syncthreads();
+    }
+}
+
+
+}  // namespace ipkgpu

@@ -1,0 +1,201 @@
+// kernels_keymajor.hpp -- dense per-group tables -> key-major database parts, and their merge.
+//
+// Device analogue of the tail of explore_group (ipk/src/db_builder.cpp:685-694:
+// `_phylo_kmer_db.unsafe_insert(kmer, {branch, score})` group after group) and of the on-disk path's
+// k-mer-keyed partition + merge (branch_group.cpp:45-70,104-107; db_builder.cpp:340-458):
+//
+//   part   for owner o of P: for every k-mer code x with x % P == o (ascending), the entries
+//          (branch id, score) of the groups that scored x, in group order.
+//          counts[o][x / P] = number of entries; entries laid out owner-major, then key, then group.
+//   merge  concatenates, per key, the entries of S sources (ranks in rank order, or batches in batch
+//          order) -- i.e. global group order, the order the reference appends them.
+//
+// Everything is a coalesced sweep of the dense tables: no sort, no global atomics.
+#pragma once
+#include "dcla_device.hpp"
+
+namespace ipkgpu {
+
+// counts_perm[(x % P) * slots + x / P] = #groups g in [0, G) with table[g][x] != 0
+__global__ __launch_bounds__(256) void km_count_kernel(const uint32_t* __restrict__ table, uint64_t T, uint32_t G,
+                                                       uint32_t P, uint64_t slots, uint32_t* __restrict__ counts)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= T) return;
+    uint32_t c = 0;
+    const uint32_t* t = table + x;
+    uint32_t g = 0;
+    for (; g + 4 <= G; g += 4) {
+        const uint32_t v0 = t[(size_t)(g + 0) * T], v1 = t[(size_t)(g + 1) * T];
+        const uint32_t v2 = t[(size_t)(g + 2) * T], v3 = t[(size_t)(g + 3) * T];
+        c += (v0 != 0u) + (v1 != 0u) + (v2 != 0u) + (v3 != 0u);
+    }
+    for (; g < G; ++g) c += (t[(size_t)g * T] != 0u);
+    const uint64_t o = x % P, q = x / P;
+    counts[o * slots + q] = c;               // padded slots (q * P + o >= T) stay at their memset 0
+}
+
+// ---- generic exclusive scan of u32 -> u64 (three kernels) -------------------------------------
+constexpr uint32_t SCAN_BLOCK = 4096;
+
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint32_t* __restrict__ in, uint64_t n,
+                                                              uint32_t* __restrict__ sums)
+{
+    __shared__ uint32_t wsum[4];
+    const uint64_t s0 = (uint64_t)blockIdx.x * SCAN_BLOCK;
+    const uint32_t m = (uint32_t)min((uint64_t)SCAN_BLOCK, n - s0);
+    uint32_t acc = 0;
+    for (uint32_t i = threadIdx.x; i < m; i += 256) acc += in[s0 + i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// out[i] = block_off[i / SCAN_BLOCK] + sum(in[block start .. i)); thread t owns 16 consecutive items
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* __restrict__ in, uint64_t n,
+                                                         const uint64_t* __restrict__ block_off,
+                                                         uint64_t* __restrict__ out)
+{
+    __shared__ uint32_t tsum[256];
+    const uint64_t s0 = (uint64_t)blockIdx.x * SCAN_BLOCK;
+    const uint32_t m = (uint32_t)min((uint64_t)SCAN_BLOCK, n - s0);
+    constexpr uint32_t PER = SCAN_BLOCK / 256;
+    const uint32_t lo = threadIdx.x * PER;
+    uint32_t v[PER];
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) { v[i] = (lo + i < m) ? in[s0 + lo + i] : 0u; acc += v[i]; }
+    tsum[threadIdx.x] = acc;
+    __syncthreads();
+    // exclusive scan of the 256 thread sums (Hillis-Steele in LDS)
+    uint32_t x = acc;
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t y = (threadIdx.x >= d) ? tsum[threadIdx.x - d] : 0u;
+        __syncthreads();
+        x += y; tsum[threadIdx.x] = x;
+        __syncthreads();
+    }
+    uint64_t run = block_off[blockIdx.x] + (uint64_t)(x - acc);
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) { if (lo + i < m) out[s0 + lo + i] = run; run += v[i]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = block_off[blockIdx.x] + (uint64_t)x;
+}
+
+// ---- write the entries of a batch of groups, key-major --------------------------------------------
+// Workgroup = 64 consecutive k-mer codes x 64 groups at a time, transposed through LDS so that a
+// wavefront emits one key's entries (<= 64 per step) as one contiguous run.  `cursor` holds, per
+// (owner, slot), the position of the key's next entry; it starts as the exclusive scan of the counts
+// and is advanced, so batches of groups append in order.
+__global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restrict__ table, uint64_t T, uint32_t G,
+                                                       const uint32_t* __restrict__ branch_of_group, uint32_t P,
+                                                       uint64_t slots, uint64_t* __restrict__ cursor,
+                                                       uint2* __restrict__ entries)
+{
+    __shared__ uint32_t tile[64][65];
+    __shared__ uint64_t run[64];
+    const uint64_t x0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    if (threadIdx.x < 64) {
+        const uint64_t x = x0 + threadIdx.x;
+        run[threadIdx.x] = (x < T) ? cursor[(x % P) * slots + x / P] : 0;
+    }
+    for (uint32_t g0 = 0; g0 < G; g0 += 64) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 4096; i += 256) {
+            const uint32_t gl = i >> 6, xl = i & 63u;
+            uint32_t v = 0;
+            if (g0 + gl < G && x0 + xl < T) v = table[(size_t)(g0 + gl) * T + x0 + xl];
+            tile[gl][xl] = v;
+        }
+        __syncthreads();
+        const uint32_t br = (g0 + lane < G) ? branch_of_group[g0 + lane] : 0u;
+        for (uint32_t xl = wave; xl < 64; xl += 4) {
+            const uint32_t v = tile[lane][xl];
+            const uint64_t m = __ballot(v != 0u);
+            if (m == 0) continue;
+            const uint64_t base = run[xl];
+            if (v != 0u) entries[base + mbcnt(m)] = make_uint2(br, dec_score_bits(v));
+            if (lane == 0) run[xl] = base + (uint64_t)__popcll(m);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint64_t x = x0 + threadIdx.x;
+        if (x < T) cursor[(x % P) * slots + x / P] = run[threadIdx.x];
+    }
+}
+
+// ---- merge of S sources for one owner -----------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_sum_counts_kernel(const uint32_t* __restrict__ counts, uint32_t S,
+                                                               uint64_t slots, uint32_t* __restrict__ total,
+                                                               uint32_t* __restrict__ flags)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= slots) return;
+    uint32_t c = 0;
+    for (uint32_t s = 0; s < S; ++s) c += counts[(size_t)s * slots + q];
+    total[q] = c;
+    flags[q] = (c != 0u);
+}
+
+// One wavefront per slot: copies the slot's entries of every source, in source order.
+// src_off[s][q] = exclusive scan of source s's counts (+ its base in `src`).
+__global__ __launch_bounds__(256) void merge_copy_kernel(const uint32_t* __restrict__ counts, uint32_t S, uint64_t slots,
+                                                         const uint64_t* __restrict__ src_off,   // [S][slots+1]
+                                                         const uint2* __restrict__ src,
+                                                         const uint64_t* __restrict__ dst_off,   // [slots+1]
+                                                         uint2* __restrict__ dst)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= slots) return;
+    const uint32_t lane = lane_id();
+    uint64_t d = dst_off[q];
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint32_t n = counts[(size_t)s * slots + q];
+        const uint64_t so = src_off[(size_t)s * (slots + 1) + q];
+        for (uint32_t i = lane; i < n; i += 64) dst[d + i] = src[so + i];
+        d += n;
+    }
+}
+
+__global__ void add_base_kernel(uint64_t* __restrict__ v, uint64_t n, uint64_t base)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] += base;
+}
+
+template <int SIGMA>
+__device__ __forceinline__ uint32_t pack_code_km(uint32_t dense, int k)
+{
+    if constexpr (SIGMA == 4) { (void)k; return dense; }
+    else {
+        uint32_t key = 0;
+        for (int d = 0; d < k; ++d) {
+            const uint32_t q = dense / SIGMA;
+            key |= (dense - q * SIGMA) << (5 * d);
+            dense = q;
+        }
+        return key;
+    }
+}
+
+// keys[j], key_off[j] for the j-th non-empty slot (flag_off = exclusive scan of flags)
+template <int SIGMA>
+__global__ __launch_bounds__(256) void merge_write_keys_kernel(const uint32_t* __restrict__ total,
+                                                               const uint64_t* __restrict__ flag_off,
+                                                               const uint64_t* __restrict__ dst_off, uint64_t slots,
+                                                               uint32_t owner, uint32_t P, int k,
+                                                               uint32_t* __restrict__ keys, uint64_t* __restrict__ key_off)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q > slots) return;
+    if (q == slots) { key_off[flag_off[slots]] = dst_off[slots]; return; }
+    if (total[q] != 0u) {
+        const uint64_t j = flag_off[q];
+        keys[j] = pack_code_km<SIGMA>((uint32_t)(q * P + owner), k);
+        key_off[j] = dst_off[q];
+    }
+}
+
+}  // namespace ipkgpu

@@ -227,3 +227,218 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+# ---- key-major parts / database shards (multi-GPU exchange step) ---------------------------------
+
+def _bind_keymajor(L):
+    if getattr(L, "_km_bound", False):
+        return
+    u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.ipkgpu_score_groups_keymajor_device.restype = C.c_int
+    L.ipkgpu_score_groups_keymajor_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u32p,
+                                                      C.c_uint32, C.c_float, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.ipkgpu_parts_num_owners.restype = C.c_uint32
+    L.ipkgpu_parts_num_owners.argtypes = [C.c_void_p]
+    L.ipkgpu_parts_slots.restype = C.c_uint64
+    L.ipkgpu_parts_slots.argtypes = [C.c_void_p]
+    L.ipkgpu_parts_counts_device.restype = C.c_void_p
+    L.ipkgpu_parts_counts_device.argtypes = [C.c_void_p]
+    L.ipkgpu_parts_entries_device.restype = C.c_void_p
+    L.ipkgpu_parts_entries_device.argtypes = [C.c_void_p]
+    L.ipkgpu_parts_owner_offsets.restype = u64p
+    L.ipkgpu_parts_owner_offsets.argtypes = [C.c_void_p]
+    L.ipkgpu_parts_emitted.restype = C.c_uint64
+    L.ipkgpu_parts_emitted.argtypes = [C.c_void_p]
+    L.ipkgpu_parts_time_ms.restype = C.c_double
+    L.ipkgpu_parts_time_ms.argtypes = [C.c_void_p, C.c_int]
+    L.ipkgpu_parts_free.restype = None
+    L.ipkgpu_parts_free.argtypes = [C.c_void_p]
+    L.ipkgpu_merge_parts.restype = C.c_int
+    L.ipkgpu_merge_parts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, u64p, C.POINTER(C.c_void_p)]
+    L.ipkgpu_db_num_keys.restype = C.c_uint64
+    L.ipkgpu_db_num_keys.argtypes = [C.c_void_p]
+    L.ipkgpu_db_num_entries.restype = C.c_uint64
+    L.ipkgpu_db_num_entries.argtypes = [C.c_void_p]
+    L.ipkgpu_db_keys.restype = u32p
+    L.ipkgpu_db_keys.argtypes = [C.c_void_p]
+    L.ipkgpu_db_key_offsets.restype = u64p
+    L.ipkgpu_db_key_offsets.argtypes = [C.c_void_p]
+    L.ipkgpu_db_entries.restype = u32p
+    L.ipkgpu_db_entries.argtypes = [C.c_void_p]
+    for n in ("ipkgpu_db_keys_device", "ipkgpu_db_key_offsets_device", "ipkgpu_db_entries_device"):
+        getattr(L, n).restype = C.c_void_p
+        getattr(L, n).argtypes = [C.c_void_p]
+    L.ipkgpu_db_time_ms.restype = C.c_double
+    L.ipkgpu_db_time_ms.argtypes = [C.c_void_p]
+    L.ipkgpu_db_free.restype = None
+    L.ipkgpu_db_free.argtypes = [C.c_void_p]
+    L._km_bound = True
+
+
+ABI_SYMBOLS += [
+    "ipkgpu_score_groups_keymajor_device", "ipkgpu_parts_num_owners", "ipkgpu_parts_slots",
+    "ipkgpu_parts_counts_device", "ipkgpu_parts_entries_device", "ipkgpu_parts_owner_offsets",
+    "ipkgpu_parts_emitted", "ipkgpu_parts_time_ms", "ipkgpu_parts_free", "ipkgpu_merge_parts",
+    "ipkgpu_db_num_keys", "ipkgpu_db_num_entries", "ipkgpu_db_keys", "ipkgpu_db_key_offsets", "ipkgpu_db_entries",
+    "ipkgpu_db_keys_device", "ipkgpu_db_key_offsets_device", "ipkgpu_db_entries_device", "ipkgpu_db_time_ms",
+    "ipkgpu_db_free",
+]
+
+
+class Parts:
+    """This rank's key-major partial database, split by owner (device resident)."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+        self.n_owners = int(lib.ipkgpu_parts_num_owners(handle))
+        self.slots = int(lib.ipkgpu_parts_slots(handle))
+        self.owner_offsets = np.ctypeslib.as_array(lib.ipkgpu_parts_owner_offsets(handle), shape=(self.n_owners + 1,)).copy()
+        self.emitted = int(lib.ipkgpu_parts_emitted(handle))
+
+    @property
+    def num_entries(self):
+        return int(self.owner_offsets[-1])
+
+    def counts_ptr(self):
+        return self._lib.ipkgpu_parts_counts_device(self._h)
+
+    def entries_ptr(self):
+        return self._lib.ipkgpu_parts_entries_device(self._h)
+
+    def time_ms(self, which):
+        return float(self._lib.ipkgpu_parts_time_ms(self._h, which))
+
+    def counts_tensor(self):
+        """torch view [n_owners, slots] int32 of the device counts (keeps self alive)."""
+        return _device_tensor(self.counts_ptr(), (self.n_owners, self.slots), "int32", self)
+
+    def entries_tensor(self):
+        """torch view [num_entries, 2] int32 (branch, score bits)."""
+        return _device_tensor(self.entries_ptr(), (max(self.num_entries, 0), 2), "int32", self)
+
+    def free(self):
+        if self._h:
+            self._lib.ipkgpu_parts_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Db:
+    """One owner's shard of the phylo-k-mer database: key -> [(branch, score)] in reference order."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+        self.num_keys = int(lib.ipkgpu_db_num_keys(handle))
+        self.num_entries = int(lib.ipkgpu_db_num_entries(handle))
+
+    def time_ms(self):
+        return float(self._lib.ipkgpu_db_time_ms(self._h))
+
+    def keys(self):
+        if self.num_keys == 0:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array(self._lib.ipkgpu_db_keys(self._h), shape=(self.num_keys,))
+
+    def key_offsets(self):
+        return np.ctypeslib.as_array(self._lib.ipkgpu_db_key_offsets(self._h), shape=(self.num_keys + 1,))
+
+    def entries(self):
+        """(branches u32 [n], scores f32 [n])"""
+        if self.num_entries == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.float32)
+        e = np.ctypeslib.as_array(self._lib.ipkgpu_db_entries(self._h), shape=(self.num_entries, 2))
+        return e[:, 0].copy(), e[:, 1].copy().view(np.float32)
+
+    def keys_device_ptr(self):
+        return self._lib.ipkgpu_db_keys_device(self._h)
+
+    def key_offsets_device_ptr(self):
+        return self._lib.ipkgpu_db_key_offsets_device(self._h)
+
+    def entries_device_ptr(self):
+        return self._lib.ipkgpu_db_entries_device(self._h)
+
+    def free(self):
+        if self._h:
+            self._lib.ipkgpu_db_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _device_tensor(ptr, shape, dtype, owner):
+    """Zero-copy torch view of engine-owned device memory via __cuda_array_interface__."""
+    import torch
+
+    n = int(np.prod(shape))
+    if n == 0 or not ptr:
+        return torch.empty(shape, dtype=getattr(torch, dtype), device="cuda")
+
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<i4", "data": (int(ptr), False),
+                                  "version": 3, "strides": None}
+    h._owner = owner
+    t = torch.as_tensor(h, device="cuda")
+    t._ipk_owner = owner
+    return t
+
+
+def _score_groups_keymajor(self, logp, mat_group, k, log_eps, n_owners=1, sigma=None, sites=None, n_mats=None):
+    """Scoring pass with key-major, owner-split output (see include/ipkgpu.h). logp: torch CUDA tensor
+    [n_mats, sites, sigma] float32 or a raw device pointer with explicit shape."""
+    _bind_keymajor(self._lib)
+    mat_group = np.ascontiguousarray(mat_group, dtype=np.uint32)
+    keep = None
+    if isinstance(logp, np.ndarray):
+        import torch
+        keep = torch.from_numpy(np.ascontiguousarray(logp, dtype=np.float32)).cuda()
+        logp = keep
+    if hasattr(logp, "data_ptr"):
+        if not logp.is_cuda or not logp.is_contiguous() or logp.dtype.itemsize != 4:
+            raise ValueError("device path needs a contiguous float32 CUDA tensor")
+        n_mats, sites, sigma = logp.shape
+        ptr = logp.data_ptr()
+        import torch
+        torch.cuda.current_stream().synchronize()
+    else:
+        ptr = int(logp)
+    out = C.c_void_p()
+    rc = self._lib.ipkgpu_score_groups_keymajor_device(self._h, C.c_void_p(ptr), n_mats, sites, sigma,
+                                                       mat_group.ctypes.data_as(C.POINTER(C.c_uint32)), k,
+                                                       C.c_float(log_eps), n_owners, C.byref(out))
+    del keep
+    if rc != 0:
+        raise self._err(rc)
+    return Parts(self._lib, out)
+
+
+def _merge_parts(self, sigma, k, owner, n_owners, counts, entries, source_offsets):
+    """counts: device tensor/pointer u32 [n_sources, slots]; entries: device tensor/pointer [n, 2];
+    source_offsets: entry offset of each source's block inside `entries` (host, length n_sources)."""
+    _bind_keymajor(self._lib)
+    so = np.ascontiguousarray(source_offsets, dtype=np.uint64)
+    cp = counts.data_ptr() if hasattr(counts, "data_ptr") else int(counts)
+    ep = entries.data_ptr() if hasattr(entries, "data_ptr") else int(entries or 0)
+    out = C.c_void_p()
+    rc = self._lib.ipkgpu_merge_parts(self._h, sigma, k, owner, n_owners, len(so), C.c_void_p(cp), C.c_void_p(ep),
+                                      so.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(out))
+    if rc != 0:
+        raise self._err(rc)
+    return Db(self._lib, out)
+
+
+Engine.score_groups_keymajor = _score_groups_keymajor
+Engine.merge_parts = _merge_parts
