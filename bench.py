@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- scored phylo-k-mers/s of the hot path on N MI355X (one process per GPU).
 
-A step = one pass of the hot path (prefix array + DCLA scoring + per-branch max-reduce + compaction
-to the sorted per-branch (key, score) sets) over the whole synthetic workload of this rank, with
-the matrices already resident in HBM.  Default workload: BASELINE.json configs[1]
+A step = one pass of the hot path over the whole synthetic workload of this rank, matrices already
+resident in HBM: prefix array + DCLA scoring + per-branch max-reduce + assembly of the key-major
+phylo-k-mer database (what `_phylo_kmer_db` holds after explore_kmers, db_builder.cpp:576-698); with
+N > 1 ranks the database is sharded by k-mer owner and the step includes the all-to-all exchange
+(RCCL) and merge.  `--output group` times the group-major form (sorted (key, score) set per branch).  Default workload: BASELINE.json configs[1]
 ("Synthetic DNA: 2000 extended nodes x 10000 sites, k=10, omega=1.5, 1xMI355X").
 Branch groups shard across ranks with no data-path collective -> weak scaling (every rank scores
 its own 1000 groups).
@@ -30,6 +32,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
     ap.add_argument("--groups", type=int, default=0, help="override the number of branch groups (0 = config's)")
     ap.add_argument("--alpha", type=float, default=0.0, help="override the column concentration")
+    ap.add_argument("--output", default="db", choices=["db", "group"], help="db: key-major database shard; group: per-branch CSR")
     ap.add_argument("--cpu-groups", type=int, default=-1, help="groups timed on the CPU oracle (-1 = auto, 0 = skip)")
     args = ap.parse_args()
 
@@ -79,21 +82,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    emitted = entries = 0
+    from ipk_amd import distributed as D
+    acc = {"score": 0.0, "launches": 0.0, "total": 0.0, "compact": 0.0, "prefix": 0.0, "merge": 0.0}
+    emitted = entries = n_keys = 0
+
+    def step(record):
+        nonlocal emitted, entries, n_keys
+        if args.output == "group":
+            r = eng.score_groups(d_logp, groups, k, eps)      # returns after the device work completed
+            emitted, entries = r.emitted, r.num_entries
+            t = r
+        else:
+            db, t = D.build_db_shard(eng, d_logp, groups, k, eps, sigma, dist if world > 1 else None, world, rank)
+            emitted, entries, n_keys = t.emitted, db.num_entries, db.num_keys
+            if record:
+                acc["merge"] += db.time_ms()
+            db.free()
+        if record:
+            acc["score"] += t.time_ms(E.T_SCORE); acc["launches"] += t.time_ms(E.T_SCORE_LAUNCHES)
+            acc["total"] += t.time_ms(E.T_TOTAL); acc["compact"] += t.time_ms(E.T_COMPACT); acc["prefix"] += t.time_ms(E.T_PREFIX)
+        t.free()
+
     for _ in range(args.warmup):
-        r = eng.score_groups(d_logp, groups, k, eps)
-        emitted, entries = r.emitted, r.num_entries
-        r.free()
+        step(False)
     barrier()
     t_start = time.perf_counter()
-    score_ms = launches = total_ms = compact_ms = prefix_ms = 0.0
     for _ in range(args.steps):
-        r = eng.score_groups(d_logp, groups, k, eps)      # returns after the device work completed
-        emitted, entries = r.emitted, r.num_entries
-        score_ms += r.time_ms(E.T_SCORE); launches += r.time_ms(E.T_SCORE_LAUNCHES)
-        total_ms += r.time_ms(E.T_TOTAL); compact_ms += r.time_ms(E.T_COMPACT); prefix_ms += r.time_ms(E.T_PREFIX)
-        r.free()
+        step(True)
     barrier()
+    score_ms, launches, total_ms, compact_ms, prefix_ms = acc["score"], acc["launches"], acc["total"], acc["compact"], acc["prefix"]
     elapsed = time.perf_counter() - t_start
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -121,13 +138,15 @@ def main():
                                    f"({ng} branch groups x {mpg}) x {sites} sites, k={k}, omega={cfg['omega']}, "
                                    f"alpha={cfg['alpha']}, per GPU",
                        "scored_per_step_per_gpu": emitted, "branch_kmer_entries_per_gpu": entries,
-                       "sharding": f"branch groups over {world} rank(s), no collective"},
+                       "output": "key-major database shard" if args.output == "db" else "group-major CSR",
+                       "sharding": f"branch groups over {world} rank(s)" + ("; k-mer-keyed all-to-all (RCCL) + merge" if world > 1 and args.output == "db" else "; no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "score_tiles_kernel (+ score_overflow_kernel)", "avg_launch_ms": avg_score_ms,
                          "algorithmic_bytes_per_launch": b_alg},
             "phases_ms_per_step": {"prefix": prefix_ms / args.steps, "score": score_ms / args.steps,
-                                   "compact": compact_ms / args.steps, "device_total": total_ms / args.steps},
+                                   "compact": compact_ms / args.steps, "device_total": total_ms / args.steps,
+                                   "db_merge": acc["merge"] / args.steps},
             "setup_s": {"synth_and_upload": t_gen},
         }
         # CPU baseline: the oracle (C restatement), 1 thread, bounded sample of the same workload

@@ -177,6 +177,9 @@ void ipkgpu_parts_free(ipkgpu_parts* p);
 int ipkgpu_merge_parts(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, uint32_t n_owners,
                        uint32_t n_sources, const uint32_t* counts_dev, const void* entries_dev,
                        const uint64_t* source_offsets, ipkgpu_db** out);
+/* Single-GPU shortcut (n_owners == 1): the parts already ARE the database; produces the key list and
+ * MOVES the entry array out of `parts` (which stays valid for its counts/timings, entries become NULL). */
+int ipkgpu_db_from_parts(ipkgpu_ctx* ctx, ipkgpu_parts* parts, uint32_t sigma, uint32_t k, ipkgpu_db** out);
 uint64_t ipkgpu_db_num_keys(const ipkgpu_db* d);
 uint64_t ipkgpu_db_num_entries(const ipkgpu_db* d);
 /* host copies (made on first use): keys u32[num_keys], key_offsets u64[num_keys+1], entries u32[num_entries][2] */

@@ -848,6 +848,58 @@ int ipkgpu_merge_parts(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t own
     return IPKGPU_OK;
 }
 
+int ipkgpu_db_from_parts(ipkgpu_ctx* ctx, ipkgpu_parts* parts, uint32_t sigma, uint32_t k, ipkgpu_db** out)
+{
+    if (!ctx) return IPKGPU_ERR_INVALID;
+    if (!out) return fail(ctx, IPKGPU_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!parts || parts->n_owners != 1 || !parts->d_counts) return fail(ctx, IPKGPU_ERR_INVALID, "parts must be single-owner and not yet consumed");
+    if ((sigma != 4 && sigma != 20) || k < 2 || k > ipkgpu_max_k(sigma) || parts->slots != ipow(sigma, (int)k))
+        return fail(ctx, IPKGPU_ERR_INVALID, "sigma/k do not match the parts");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ipkgpu_db* db = new (std::nothrow) ipkgpu_db();
+    if (!db) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
+    db->ctx = ctx;
+    struct Guard { ipkgpu_db* r; ~Guard() { if (r) ipkgpu_db_free(r); } } guard{db};
+    const uint64_t slots = parts->slots;
+    Stopwatch sw(ctx->stream);
+    const int t0 = sw.mark();
+    // single source, single owner: the entries are already in database order; only the key list
+    // (non-empty slots) and its offsets have to be produced
+    RC_TRY(ensure(ctx, ctx->tmp_a, slots * 4));
+    RC_TRY(ensure(ctx, ctx->tmp_b, (slots + 1) * 8));
+    RC_TRY(ensure(ctx, ctx->counts, slots * 4));
+    RC_TRY(ensure(ctx, ctx->offsets, (slots + 1) * 8));
+    hipLaunchKernelGGL(merge_sum_counts_kernel, dim3((uint32_t)((slots + 255) / 256)), dim3(256), 0, ctx->stream,
+                       parts->d_counts, 1u, slots, ctx->counts.as<uint32_t>(), ctx->tmp_a.as<uint32_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    RC_TRY(scan_u32(ctx, parts->d_counts, slots, ctx->tmp_b.as<uint64_t>()));
+    RC_TRY(scan_u32(ctx, ctx->tmp_a.as<uint32_t>(), slots, ctx->offsets.as<uint64_t>()));
+    uint64_t n_keys = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_keys, ctx->offsets.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMalloc((void**)&db->d_keys, std::max<uint64_t>(n_keys, 1) * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&db->d_key_off, (n_keys + 1) * 8));
+    const uint32_t nbk = (uint32_t)((slots + 1 + 255) / 256);
+    if (sigma == 4)
+        hipLaunchKernelGGL(merge_write_keys_kernel<4>, dim3(nbk), dim3(256), 0, ctx->stream, ctx->counts.as<uint32_t>(),
+                           ctx->offsets.as<uint64_t>(), ctx->tmp_b.as<uint64_t>(), slots, 0u, 1u, (int)k, db->d_keys, db->d_key_off);
+    else
+        hipLaunchKernelGGL(merge_write_keys_kernel<20>, dim3(nbk), dim3(256), 0, ctx->stream, ctx->counts.as<uint32_t>(),
+                           ctx->offsets.as<uint64_t>(), ctx->tmp_b.as<uint64_t>(), slots, 0u, 1u, (int)k, db->d_keys, db->d_key_off);
+    HIP_TRY(ctx, hipGetLastError());
+    const int t1 = sw.mark();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    db->n_keys = n_keys;
+    db->n_entries = parts->owner_off[1];
+    db->d_entries = parts->d_entries;          // ownership moves to the database
+    parts->d_entries = nullptr;
+    db->t_merge = sw.ms(t0, t1);
+    guard.r = nullptr;
+    *out = db;
+    return IPKGPU_OK;
+}
+
 uint64_t ipkgpu_db_num_keys(const ipkgpu_db* d) { return d ? d->n_keys : 0; }
 uint64_t ipkgpu_db_num_entries(const ipkgpu_db* d) { return d ? d->n_entries : 0; }
 const uint32_t* ipkgpu_db_keys_device(const ipkgpu_db* d) { return d ? d->d_keys : nullptr; }

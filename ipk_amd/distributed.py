@@ -50,6 +50,8 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
     """Scores this rank's groups and returns (this rank's database shard, parts) -- the state
     `_phylo_kmer_db` has after explore_kmers (db_builder.cpp:576-627), sharded by k-mer owner."""
     parts = engine.score_groups_keymajor(logp, mat_group, k, log_eps, n_owners=world)
+    if world == 1:
+        return engine.db_from_parts(parts, sigma, k), parts
     counts, entries = parts.counts_tensor(), parts.entries_tensor()
     rc, re_, so = exchange_parts(counts, entries, parts.owner_offsets, dist, world)
     if world > 1:

@@ -257,6 +257,8 @@ def _bind_keymajor(L):
     L.ipkgpu_merge_parts.restype = C.c_int
     L.ipkgpu_merge_parts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_void_p, u64p, C.POINTER(C.c_void_p)]
+    L.ipkgpu_db_from_parts.restype = C.c_int
+    L.ipkgpu_db_from_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.ipkgpu_db_num_keys.restype = C.c_uint64
     L.ipkgpu_db_num_keys.argtypes = [C.c_void_p]
     L.ipkgpu_db_num_entries.restype = C.c_uint64
@@ -283,7 +285,7 @@ ABI_SYMBOLS += [
     "ipkgpu_parts_emitted", "ipkgpu_parts_time_ms", "ipkgpu_parts_free", "ipkgpu_merge_parts",
     "ipkgpu_db_num_keys", "ipkgpu_db_num_entries", "ipkgpu_db_keys", "ipkgpu_db_key_offsets", "ipkgpu_db_entries",
     "ipkgpu_db_keys_device", "ipkgpu_db_key_offsets_device", "ipkgpu_db_entries_device", "ipkgpu_db_time_ms",
-    "ipkgpu_db_free",
+    "ipkgpu_db_free", "ipkgpu_db_from_parts",
 ]
 
 
@@ -440,5 +442,17 @@ def _merge_parts(self, sigma, k, owner, n_owners, counts, entries, source_offset
     return Db(self._lib, out)
 
 
+def _db_from_parts(self, parts, sigma, k):
+    """Single-owner parts -> database without copying the entries (they move into the Db)."""
+    _bind_keymajor(self._lib)
+    out = C.c_void_p()
+    rc = self._lib.ipkgpu_db_from_parts(self._h, parts._h, sigma, k, C.byref(out))
+    if rc != 0:
+        raise self._err(rc)
+    parts.owner_offsets = parts.owner_offsets.copy()
+    return Db(self._lib, out)
+
+
+Engine.db_from_parts = _db_from_parts
 Engine.score_groups_keymajor = _score_groups_keymajor
 Engine.merge_parts = _merge_parts
