@@ -76,6 +76,8 @@ def main():
     eng = ipk_amd.Engine(local_rank)
     if os.environ.get("IPKGPU_VARIANT"):
         eng.set_option("variant", int(os.environ["IPKGPU_VARIANT"]))   # diagnostics only
+    if os.environ.get("IPKGPU_DEBUG_FLAGS"):
+        eng.set_option("debug_flags", int(os.environ["IPKGPU_DEBUG_FLAGS"]))
 
     def barrier():
         if world > 1:

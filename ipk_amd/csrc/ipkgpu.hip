@@ -53,7 +53,10 @@ struct ipkgpu_ctx {
     int64_t workspace_bytes = 0;
     int64_t opt_list_cap = 0;
     int64_t opt_variant = 0;
+    int64_t opt_flags = 0;
     DevBuf table, best, ovfq, counts, offsets, goff, idx, branch, scan_sums, scan_boff, tmp_a, tmp_b, tmp_c;
+    DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
+    double pairs_per_window = 0;      // calibration of the pair pool from the previous call
     void* small = nullptr;            // emitted (u64) @0, ovf_count (u32) @16
     int num_cu = 256;
 };
@@ -207,7 +210,8 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
-                      &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c};
+                      &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
+                      &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->small) (void)hipFree(ctx->small);
     (void)hipStreamDestroy(ctx->stream);
@@ -224,6 +228,7 @@ int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value)
     }
     if (!strcmp(name, "list_cap")) { ctx->opt_list_cap = value; return IPKGPU_OK; }
     if (!strcmp(name, "variant")) { ctx->opt_variant = value; return IPKGPU_OK; }
+    if (!strcmp(name, "debug_flags")) { ctx->opt_flags = value; return IPKGPU_OK; }
     return fail(ctx, IPKGPU_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -282,6 +287,114 @@ int launch_both(ipkgpu_ctx* ctx, const ScoreParams& p)
     int rc = launch_score<SIGMA, K>(ctx, p);
     if (rc) return rc;
     return launch_overflow<SIGMA, K>(ctx, p);
+}
+
+
+// ---- stream variant (two-pass radix max-reduce) ----------------------------------------------------
+template <int SIGMA, int K> constexpr uint32_t stream_tbl()
+{
+    constexpr uint64_t T = ipow(SIGMA, K);
+    if (Geo<SIGMA, K, 1 << 30>::DIRECT) return 0;                       // sigma^k <= 64: nothing to gain
+    if (SIGMA == 4) return T <= 16384 ? (uint32_t)T : (K <= 10 ? 16384u : 32768u);
+    if (K <= 3) return (uint32_t)T;                                     // 400, 8000
+    if (K <= 5) return 32000u;                                          // 20^4 = 5 x 32000, 20^5 = 100 x 32000
+    return 0;                                                           // AA k=6: 2000 buckets per group -> atomics variant
+}
+
+struct StreamLaunch {
+    uint32_t g0, gb;               // groups of the batch
+    uint32_t n_waves_total;
+    uint32_t S;
+};
+
+template <int SIGMA, int K>
+int launch_stream_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
+{
+    constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
+    if constexpr (TBL == 0) { (void)sp; (void)n_wg; return fail(ctx, IPKGPU_ERR_INVALID, "stream variant unsupported for this sigma/k"); }
+    else {
+        constexpr int CAP = fast_cap<SIGMA, K>();
+        constexpr uint32_t T = ipow(SIGMA, K);
+        constexpr uint32_t NB = (T + TBL - 1) / TBL;
+        constexpr size_t lds = TileGeo<SIGMA, K, TW>::HEAD_BYTES + (size_t)NW * wave_scratch_entries<SIGMA, K, CAP>() * 8 + (size_t)NW * 2 * NB * 4;
+        static_assert(lds <= 160 * 1024, "stream pass-1 LDS budget");
+        auto kern = score_stream_kernel<SIGMA, K, CAP, TW, NW, TBL>;
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NW * 64), lds, ctx->stream, sp);
+        HIP_TRY(ctx, hipGetLastError());
+        return IPKGPU_OK;
+    }
+}
+
+template <int SIGMA, int K>
+int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* table)
+{
+    constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
+    if constexpr (TBL == 0) { (void)n_gb; (void)T; (void)table; return fail(ctx, IPKGPU_ERR_INVALID, "stream variant unsupported"); }
+    else {
+        constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+        constexpr int NT = TBL <= 16384 ? 512 : 1024;
+        constexpr size_t lds = (size_t)TBL * 4;
+        auto kern = reduce_buckets_kernel<TBL, NT>;
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(), ctx->desc.as<unsigned long long>(),
+                           ctx->gboff.as<uint64_t>(), ctx->clist.as<uint32_t>(), NB, T, table);
+        HIP_TRY(ctx, hipGetLastError());
+        return IPKGPU_OK;
+    }
+}
+
+template <int SIGMA, int K> uint32_t stream_nb() {
+    constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
+    if constexpr (TBL == 0) return 0; else return (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+}
+
+#define IPK_DISPATCH(SIGMA_V, K_V, EXPR_MACRO)                                         \
+    do {                                                                               \
+        if ((SIGMA_V) == 4) {                                                          \
+            switch (K_V) {                                                             \
+                case 2: EXPR_MACRO(4, 2); case 3: EXPR_MACRO(4, 3); case 4: EXPR_MACRO(4, 4); \
+                case 5: EXPR_MACRO(4, 5); case 6: EXPR_MACRO(4, 6); case 7: EXPR_MACRO(4, 7); \
+                case 8: EXPR_MACRO(4, 8); case 9: EXPR_MACRO(4, 9); case 10: EXPR_MACRO(4, 10); \
+                case 11: EXPR_MACRO(4, 11); case 12: EXPR_MACRO(4, 12);                \
+            }                                                                          \
+        } else if ((SIGMA_V) == 20) {                                                  \
+            switch (K_V) {                                                             \
+                case 2: EXPR_MACRO(20, 2); case 3: EXPR_MACRO(20, 3); case 4: EXPR_MACRO(20, 4); \
+                case 5: EXPR_MACRO(20, 5); case 6: EXPR_MACRO(20, 6);                  \
+            }                                                                          \
+        }                                                                              \
+    } while (0)
+
+uint32_t stream_buckets(uint32_t sigma, uint32_t k)
+{
+#define M_NB(S_, K_) return stream_nb<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_NB);
+#undef M_NB
+    return 0;
+}
+int dispatch_stream_pass1(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const StreamParams& sp, uint32_t n_wg)
+{
+#define M_P1(S_, K_) return launch_stream_pass1<S_, K_>(ctx, sp, n_wg)
+    IPK_DISPATCH(sigma, k, M_P1);
+#undef M_P1
+    return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+}
+int dispatch_stream_pass2(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t n_gb, uint64_t T, uint32_t* table)
+{
+#define M_P2(S_, K_) return launch_stream_pass2<S_, K_>(ctx, n_gb, T, table)
+    IPK_DISPATCH(sigma, k, M_P2);
+#undef M_P2
+    return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+}
+int dispatch_overflow(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScoreParams& p)
+{
+#define M_OV(S_, K_) return launch_overflow<S_, K_>(ctx, p)
+    IPK_DISPATCH(sigma, k, M_OV);
+#undef M_OV
+    return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
 }
 
 int dispatch_score(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScoreParams& p)
@@ -370,9 +483,11 @@ int run_prefix(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev)
     return IPKGPU_OK;
 }
 
-// Scores groups [g0, g0 + gb) into ctx->table ([gb][table_size], zeroed here).
-int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t g0, uint32_t gb,
-                std::vector<uint32_t>& idx_host)
+int scan_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out);
+
+// Scores groups [g0, g0 + gb) into ctx->table ([gb][table_size]); *emitted_out = scored phylo-k-mers of the batch.
+int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t g0, uint32_t gb,
+                     std::vector<uint32_t>& idx_host)
 {
     const uint32_t n_mats = pl.n_mats;
     idx_host.resize((size_t)n_mats * 2);
@@ -402,9 +517,115 @@ int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t
     p.ovf_queue = ctx->ovfq.as<unsigned long long>();
     p.ovf_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 16);
     p.flags = (uint32_t)(ctx->opt_variant == 99 ? 1 : 0);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->table.p, 0, (size_t)gb * pl.table_size * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
-    return dispatch_score(ctx, pl.sigma, pl.k, p);
+    const uint32_t NBK = stream_buckets(pl.sigma, pl.k);
+    const bool use_stream = NBK != 0 && NBK <= 1024 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
+    if (!use_stream) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->table.p, 0, (size_t)gb * pl.table_size * 4, ctx->stream));
+        return dispatch_score(ctx, pl.sigma, pl.k, p);
+    }
+
+    // ---- stream variant: pass 1 (append pairs) -> chunk index -> pass 2 (LDS reduce) -> big-list windows
+    // matrices of each group of the batch (CSR)
+    std::vector<uint32_t> gm((size_t)gb + 1 + nb, 0);
+    for (uint32_t i = 0; i < n_mats; ++i)
+        if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) gm[pl.slot_of[i] - g0 + 1]++;
+    for (uint32_t g = 0; g < gb; ++g) gm[g + 1] += gm[g];
+    {
+        std::vector<uint32_t> cur(gm.begin(), gm.begin() + gb);
+        for (uint32_t i = 0; i < n_mats; ++i)
+            if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) gm[(size_t)gb + 1 + cur[pl.slot_of[i] - g0]++] = i;
+    }
+    RC_TRY(ensure(ctx, ctx->gm, gm.size() * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->gm.p, gm.data(), gm.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    // segments per group: enough workgroups to fill the chip, few enough that a wave's open chunks stay a small overhead
+    const uint32_t tiles_per_group_min = pl.tiles_per_mat;
+    uint32_t S = (uint32_t)std::max<uint64_t>(1, ((uint64_t)ctx->num_cu * 8 + gb - 1) / gb);
+    S = std::min<uint32_t>(S, std::max<uint32_t>(1, tiles_per_group_min));
+    const uint32_t n_wg = gb * S;
+    const uint64_t n_waves = (uint64_t)n_wg * NW;
+    const uint64_t windows = (uint64_t)nb * pl.nwin;
+    const uint64_t n_gb = (uint64_t)gb * NBK;
+
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const uint64_t max_chunks = std::min<uint64_t>(0xFFFFFFF0ull, (uint64_t)(free_b + ctx->pool.cap + ctx->desc.cap) * 9 / 10 / (CH * 8 + 8));
+    double ppw = ctx->pairs_per_window > 0 ? ctx->pairs_per_window * 1.25 : 256.0;
+    uint64_t want = (uint64_t)((double)windows * ppw / CH) + 2 * n_waves * NBK + n_waves * ALLOC_BATCH + 1024;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        uint64_t cap = std::min<uint64_t>(want, max_chunks);
+        if (cap < 2 * n_waves * NBK) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool does not fit device memory (lower workspace_bytes)");
+        RC_TRY(ensure(ctx, ctx->pool, cap * CH * 8));
+        RC_TRY(ensure(ctx, ctx->desc, cap * 8));
+        cap = std::min<uint64_t>(ctx->pool.cap / (CH * 8), ctx->desc.cap / 8);
+        RC_TRY(ensure(ctx, ctx->gbcnt, n_gb * 4));
+        RC_TRY(ensure(ctx, ctx->gbcur, n_gb * 4));
+        RC_TRY(ensure(ctx, ctx->gboff, (n_gb + 1) * 8));
+        uint32_t* d_pool_next = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 32);
+        uint32_t* d_pool_ovf = d_pool_next + 1;
+        HIP_TRY(ctx, hipMemsetAsync(d_pool_next, 0, 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->desc.p, 0, cap * 8, ctx->stream));   // ids drawn but never opened stay empty
+        HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(p.emitted, 0, 8, ctx->stream));      // a retry must not double count
+
+        StreamParams sp;
+        sp.logp = logp_dev; sp.best = ctx->best.as<float>();
+        sp.gm_off = ctx->gm.as<uint32_t>(); sp.gm_list = ctx->gm.as<uint32_t>() + gb + 1;
+        sp.sites = pl.sites; sp.nwin = pl.nwin; sp.tiles_per_mat = pl.tiles_per_mat; sp.S = S;
+        sp.eps = pl.eps;
+        sp.pool = ctx->pool.as<uint2>(); sp.pool_cap = (uint32_t)cap; sp.pool_next = d_pool_next;
+        sp.desc = ctx->desc.as<unsigned long long>(); sp.pool_ovf = d_pool_ovf;
+        sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count;
+        sp.flags = ctx->opt_variant == 0 ? 0u : (uint32_t)(ctx->opt_flags);
+        RC_TRY(dispatch_stream_pass1(ctx, pl.sigma, pl.k, sp, n_wg));
+        uint32_t h[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(h, d_pool_next, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h[1] != 0) {                    // pool exhausted: h[0] chunks were asked for
+            if (cap >= max_chunks) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool exhausted at the device-memory limit (lower workspace_bytes to score fewer groups per batch)");
+            want = (uint64_t)((double)h[0] * 1.1) + 1024;
+            continue;
+        }
+        const uint32_t n_used = (uint32_t)std::min<uint64_t>(h[0], cap);
+        // chunk index: chunk ids grouped by (group, bucket).  Unused/never-closed chunks have count 0 and are skipped;
+        // descriptors of this batch's chunks were all written by pass 1 (closed or flushed), stale ones are overwritten
+        // or lie beyond n_used.
+        HIP_TRY(ctx, hipMemsetAsync(ctx->gbcnt.p, 0, n_gb * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->gbcur.p, 0, n_gb * 4, ctx->stream));
+        RC_TRY(ensure(ctx, ctx->clist, std::max<uint64_t>(n_used, 1) * 4));
+        if (n_used) {
+            hipLaunchKernelGGL(chunk_hist_kernel, dim3((n_used + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->desc.as<unsigned long long>(), n_used, ctx->gbcnt.as<uint32_t>());
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        RC_TRY(scan_u32(ctx, ctx->gbcnt.as<uint32_t>(), n_gb, ctx->gboff.as<uint64_t>()));
+        if (n_used) {
+            hipLaunchKernelGGL(chunk_scatter_kernel, dim3((n_used + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->desc.as<unsigned long long>(), n_used, ctx->gboff.as<uint64_t>(), ctx->gbcur.as<uint32_t>(),
+                               ctx->clist.as<uint32_t>());
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        RC_TRY(dispatch_stream_pass2(ctx, pl.sigma, pl.k, (uint32_t)n_gb, pl.table_size, ctx->table.as<uint32_t>()));
+        // windows whose half lists overflowed the fast path: big-list kernel, max-reduced into the finished tables
+        RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
+        if (windows) ctx->pairs_per_window = (double)n_used * CH / (double)windows;
+        return IPKGPU_OK;
+    }
+    return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool could not be sized");
+}
+
+int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t g0, uint32_t gb,
+                std::vector<uint32_t>& idx_host, uint64_t* emitted_acc)
+{
+    HIP_TRY(ctx, hipMemsetAsync(ctx->small, 0, 8, ctx->stream));            // per-batch scored-k-mer counter
+    RC_TRY(score_batch_impl(ctx, pl, logp_dev, g0, gb, idx_host));
+    unsigned long long e = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&e, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *emitted_acc += e;
+    return IPKGPU_OK;
 }
 
 // out[0..n] = base + exclusive scan of in[0..n)   (u32 -> u64)
@@ -461,7 +682,7 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
     for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)pl.gpb) {
         const uint32_t gb = std::min<uint32_t>((uint32_t)pl.gpb, n_groups - g0);
         const int s0 = sw.mark();
-        RC_TRY(score_batch(ctx, pl, logp_dev, g0, gb, idx_host));
+        RC_TRY(score_batch(ctx, pl, logp_dev, g0, gb, idx_host, &res->emitted));
         const int s1 = sw.mark();
         ev_score.push_back({s0, s1});
         res->score_launches += 1;
@@ -506,10 +727,7 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
         total_entries = new_total;
     }
     const int t_end = sw.mark();
-    unsigned long long emitted = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&emitted, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    res->emitted = emitted;
     res->t_total = sw.ms(t_begin, t_end);
     res->t_prefix = sw.ms(t_begin, t_pre);
     for (auto& pr : ev_score) res->t_score += sw.ms(pr.first, pr.second);
@@ -706,7 +924,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)pl.gpb) {
         const uint32_t gb = std::min<uint32_t>((uint32_t)pl.gpb, n_groups - g0);
         const int s0 = sw.mark();
-        RC_TRY(score_batch(ctx, pl, logp_dev, g0, gb, idx_host));
+        RC_TRY(score_batch(ctx, pl, logp_dev, g0, gb, idx_host, &parts->emitted));
         const int s1 = sw.mark();
         ev_score.push_back({s0, s1});
         parts->score_launches += 1;
@@ -778,10 +996,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         ev_compact.push_back({m0, sw.mark()});
     }
     const int t_end = sw.mark();
-    unsigned long long emitted = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&emitted, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    parts->emitted = emitted;
     parts->t_total = sw.ms(t_begin, t_end);
     parts->t_prefix = sw.ms(t_begin, t_pre);
     for (auto& pr : ev_score) parts->t_score += sw.ms(pr.first, pr.second);

@@ -187,4 +187,201 @@ __global__ __launch_bounds__(64) void score_overflow_kernel(ScoreParams p)
 }
 
 
+// =================================================================================================
+// Two-pass radix max-reduce ("stream" variant): scattered global atomics run at ~25-45 G/s on MI355X
+// (memory-side, 64-byte requests) while LDS atomics run at ~1.8 T/s, so the per-branch max-reduce
+// (ipk::put, branch_group.cpp:88-101) is done in LDS.  A group's table (sigma^k slots) does not fit
+// LDS, hence:
+//   pass 1  score_stream_kernel: list building as in score_tiles_kernel; every surviving
+//           (code, score) pair is appended to a chunk of the pair pool owned by this wavefront and
+//           the pair's key bucket (bucket = code / TBL).  Chunks are CH pairs; a descriptor
+//           (group, bucket, count) is written when a chunk is closed.
+//   index   chunk_hist / scan / chunk_scatter: chunk ids sorted by (group, bucket).
+//   pass 2  reduce_buckets_kernel: one workgroup per (group, bucket) max-reduces its chunks in a
+//           TBL-slot LDS table and stores the finished table slice (plain coalesced stores).
+// =================================================================================================
+constexpr uint32_t CH = 256;                 // pairs per chunk (2 KiB)
+constexpr uint32_t CHUNK_NONE = 0xFFFFFFFFu;
+constexpr uint32_t ALLOC_BATCH = 32;         // chunk ids a wavefront draws per global atomic
+
+struct StreamParams {
+    const float* logp;
+    const float* best;
+    const uint32_t* gm_off;        // [G+1] matrices of each group of the batch (CSR)
+    const uint32_t* gm_list;       // matrix indices
+    uint32_t sites, nwin, tiles_per_mat, S;   // S = segments (workgroups) per group
+    float eps;
+    uint2* pool;                   // [pool_cap][CH] pairs (dense code, score bits)
+    uint32_t pool_cap;
+    uint32_t* pool_next;           // next free chunk
+    unsigned long long* desc;      // [pool_cap] (group * NB + bucket) << 32 | count ; 0 = unused
+    uint32_t* pool_ovf;            // set when the pool ran out (the batch is then redone)
+    unsigned long long* emitted;
+    unsigned long long* ovf_queue;
+    uint32_t* ovf_count;
+    uint32_t flags;                // diagnostics: bit 0 = skip the pool stores, bit 1 = skip the append bookkeeping too
+};
+
+template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL>
+__global__ __launch_bounds__(NW * 64) void score_stream_kernel(StreamParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    using TG = TileGeo<SIGMA, K, TW>;
+    constexpr uint32_t T = ipow(SIGMA, K);
+    constexpr uint32_t NB = (T + TBL - 1) / TBL;
+    constexpr uint32_t WS = wave_scratch_entries<SIGMA, K, CAP>();
+    float* cols = reinterpret_cast<float*>(smem);
+    float* best = cols + TG::COLS_F;
+    uint2* scratch_all = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
+    uint32_t* state_all = reinterpret_cast<uint32_t*>(scratch_all + (size_t)NW * WS);   // per wave: base[NB], fill[NB]
+
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x / p.S, seg = blockIdx.x - g * p.S;
+    const uint32_t m0 = p.gm_off[g], nm = p.gm_off[g + 1] - m0;
+    const uint32_t total_tiles = nm * p.tiles_per_mat;
+    const uint32_t t_lo = (uint32_t)(((uint64_t)total_tiles * seg) / p.S);
+    const uint32_t t_hi = (uint32_t)(((uint64_t)total_tiles * (seg + 1)) / p.S);
+
+    uint2* scratch = scratch_all + (size_t)wave * WS;
+    uint32_t* cbase = state_all + (size_t)wave * 2 * NB;
+    uint32_t* cfill = cbase + NB;
+    for (uint32_t b = lane; b < NB; b += 64) { cbase[b] = CHUNK_NONE; cfill[b] = CH; }
+    uint32_t emitted = 0;
+    uint32_t chunk_next = 0, chunk_end = 0;            // this wave's private range of free chunk ids
+
+    for (uint32_t t = t_lo; t < t_hi; ++t) {
+        const uint32_t q = t / p.tiles_per_mat, tile = t - q * p.tiles_per_mat;
+        const uint32_t mat = p.gm_list[m0 + q];
+        const uint32_t t0 = tile * TW;
+        const uint32_t nw = min((uint32_t)TW, p.nwin - t0);
+        const uint32_t ncol = nw + K - 1;
+        __syncthreads();                                   // previous tile fully consumed
+        {
+            const float4* src = reinterpret_cast<const float4*>(p.logp + ((size_t)mat * p.sites + t0) * SIGMA);
+            float4* dst = reinterpret_cast<float4*>(cols);
+            const uint32_t n4 = ncol * (SIGMA / 4);
+            for (uint32_t i = threadIdx.x; i < n4; i += NW * 64) dst[i] = src[i];
+            const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + t0;
+            for (uint32_t i = threadIdx.x; i <= ncol; i += NW * 64) best[i] = bsrc[i];
+        }
+        __syncthreads();
+        for (uint32_t w = wave; w < nw; w += NW) {
+            WinCtx c{cols, best, w};
+            const uint2 *L, *R;
+            uint32_t nL, nR;
+            static_assert(!Geo<SIGMA, K, CAP>::DIRECT, "stream variant needs k with sigma^k > 64");
+            if (!build_halves<SIGMA, K, CAP>(c, p.eps, scratch, L, nL, R, nR)) {
+                if (lane == 0) {
+                    const uint32_t qi = atomicAdd(p.ovf_count, 1u);
+                    p.ovf_queue[qi] = ((unsigned long long)mat << 32) | (unsigned long long)(t0 + w);
+                }
+                continue;
+            }
+            if (nL == 0 || nR == 0) continue;
+            constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
+            uint32_t cnt = 0;
+            for_each_pair(L, nL, R, nR, [&](bool valid, uint2 a, uint2 b) {
+                const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
+                const bool pass = valid && (s > p.eps);                            // :91
+                const uint32_t idx = a.x * mulR + b.x;
+                const uint32_t bk = pass ? idx / TBL : 0u;
+                uint32_t slot = 0, cb = CHUNK_NONE;
+                if (pass && !(p.flags & 2u)) { slot = atomicAdd(&cfill[bk], 1u); cb = cbase[bk]; }
+                const uint2 pr = make_uint2(idx, __float_as_uint(s));
+                if (pass && slot < CH && cb != CHUNK_NONE && !(p.flags & 1u)) p.pool[(size_t)cb * CH + slot] = pr;
+                const uint64_t pm = __ballot(pass);
+                cnt += (uint32_t)__popcll(pm);
+                uint64_t ovf = __ballot(pass && slot >= CH);
+                while (ovf) {                                   // a bucket's chunk filled up: open a new one
+                    const uint32_t l0 = (uint32_t)__ffsll((long long)ovf) - 1u;
+                    const uint32_t bb = __shfl(bk, (int)l0);
+                    const uint64_t m = __ballot(pass && slot >= CH && bk == bb);
+                    // chunk ids are drawn ALLOC_BATCH at a time: one returning atomic on a single word
+                    // saturates at ~88 per microsecond chip-wide, far below one per 256 pairs
+                    if (chunk_next == chunk_end) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(p.pool_next, ALLOC_BATCH);
+                        chunk_next = __shfl(base, 0);
+                        chunk_end = chunk_next + ALLOC_BATCH;
+                    }
+                    uint32_t nid = chunk_next++;
+                    if (nid >= p.pool_cap) { if (lane == 0) atomicOr(p.pool_ovf, 1u); nid = CHUNK_NONE; }
+                    wave_lds_sync();
+                    const uint32_t old_id = cbase[bb];
+                    wave_lds_sync();
+                    if (lane == 0) {
+                        if (old_id != CHUNK_NONE)
+                            p.desc[old_id] = ((unsigned long long)(g * NB + bb) << 32) | (unsigned long long)CH;
+                        cbase[bb] = nid;
+                        cfill[bb] = cfill[bb] - CH;
+                    }
+                    wave_lds_sync();
+                    if (((m >> lane) & 1ull) && nid != CHUNK_NONE) p.pool[(size_t)nid * CH + (slot - CH)] = pr;
+                    ovf &= ~m;
+                }
+            });
+            emitted += cnt;
+        }
+    }
+    // close this wave's open chunks
+    wave_lds_sync();
+    for (uint32_t b = lane; b < NB; b += 64) {
+        const uint32_t id = cbase[b];
+        if (id != CHUNK_NONE) p.desc[id] = ((unsigned long long)(g * NB + b) << 32) | (unsigned long long)min(cfill[b], CH);
+    }
+    if (lane == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
+}
+
+// chunk index: how many chunks each (group, bucket) has; then chunk ids grouped by (group, bucket)
+__global__ __launch_bounds__(256) void chunk_hist_kernel(const unsigned long long* __restrict__ desc, uint32_t n,
+                                                         uint32_t* __restrict__ cnt)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long d = desc[i];
+    if ((uint32_t)d != 0u) atomicAdd(&cnt[(uint32_t)(d >> 32)], 1u);
+}
+__global__ __launch_bounds__(256) void chunk_scatter_kernel(const unsigned long long* __restrict__ desc, uint32_t n,
+                                                            const uint64_t* __restrict__ off, uint32_t* __restrict__ cur,
+                                                            uint32_t* __restrict__ list)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long d = desc[i];
+    if ((uint32_t)d == 0u) return;
+    const uint32_t gb = (uint32_t)(d >> 32);
+    list[off[gb] + atomicAdd(&cur[gb], 1u)] = i;
+}
+
+// pass 2: one workgroup per (group, bucket): LDS max-reduce of the bucket's chunks, then the table slice
+template <uint32_t TBL, int NT>
+__global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restrict__ pool,
+                                                           const unsigned long long* __restrict__ desc,
+                                                           const uint64_t* __restrict__ off, const uint32_t* __restrict__ list,
+                                                           uint32_t NB, uint64_t T, uint32_t* __restrict__ table)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t gb = blockIdx.x;
+    const uint32_t g = gb / NB, b = gb - g * NB;
+    const uint64_t key0 = (uint64_t)b * TBL;
+    const uint32_t nslots = (uint32_t)min((uint64_t)TBL, T - key0);
+    for (uint32_t i = threadIdx.x; i < TBL; i += NT) tab[i] = 0u;
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t c0 = off[gb], c1 = off[gb + 1];
+    for (uint64_t ci = c0 + wave; ci < c1; ci += NT / 64) {
+        const uint32_t id = list[ci];
+        const uint32_t n = (uint32_t)desc[id];
+        const uint2* src = pool + (size_t)id * CH;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint2 pr = src[i];
+            atomicMax(&tab[pr.x - (uint32_t)key0], enc_score_bits(pr.y));
+        }
+    }
+    __syncthreads();
+    uint32_t* dst = table + (size_t)g * T + key0;
+    for (uint32_t i = threadIdx.x; i < nslots; i += NT) dst[i] = tab[i];
+}
+
 }  // namespace ipkgpu
