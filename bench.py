@@ -85,7 +85,7 @@ def main():
         torch.cuda.synchronize()
 
     from ipk_amd import distributed as D
-    acc = {"score": 0.0, "launches": 0.0, "total": 0.0, "compact": 0.0, "prefix": 0.0, "merge": 0.0}
+    acc = {"score": 0.0, "launches": 0.0, "total": 0.0, "compact": 0.0, "prefix": 0.0, "merge": 0.0, "main": 0.0, "reduce": 0.0}
     emitted = entries = n_keys = 0
 
     def step(record):
@@ -103,6 +103,7 @@ def main():
         if record:
             acc["score"] += t.time_ms(E.T_SCORE); acc["launches"] += t.time_ms(E.T_SCORE_LAUNCHES)
             acc["total"] += t.time_ms(E.T_TOTAL); acc["compact"] += t.time_ms(E.T_COMPACT); acc["prefix"] += t.time_ms(E.T_PREFIX)
+            acc["main"] += t.time_ms(E.T_SCORE_MAIN); acc["reduce"] += t.time_ms(E.T_SCORE_REDUCE)
         t.free()
 
     for _ in range(args.warmup):
@@ -130,8 +131,19 @@ def main():
         # roofline of the dominant kernel (scoring + max-reduce): algorithmic bytes per launch =
         # every matrix read once + one (u32 key, f32 score) pair per scored phylo-k-mer
         b_alg = n_mats * sites * sigma * 4 + 8 * emitted
+        main_kernel = "score_stream_kernel" if acc["reduce"] > 0 else "score_tiles_kernel"
         avg_score_ms = score_ms / max(launches, 1)
-        achieved = b_alg / (avg_score_ms * 1e-3) / 1e9 if avg_score_ms > 0 else 0.0
+        avg_main_ms = acc["main"] / max(launches, 1)          # the dominant kernel alone (HIP events on its stream)
+        achieved = b_alg / (avg_main_ms * 1e-3) / 1e9 if avg_main_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("workload") == args.config and tj.get("kernel", "").startswith(main_kernel.split("_kernel")[0]):
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         out = {
             "metric": "scored phylo-k-mers/sec", "value": value, "unit": "phylo-k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -143,10 +155,12 @@ def main():
                        "output": "key-major database shard" if args.output == "db" else "group-major CSR",
                        "sharding": f"branch groups over {world} rank(s)" + ("; k-mer-keyed all-to-all (RCCL) + merge" if world > 1 and args.output == "db" else "; no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "score_tiles_kernel (+ score_overflow_kernel)", "avg_launch_ms": avg_score_ms,
-                         "algorithmic_bytes_per_launch": b_alg},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": main_kernel, "avg_launch_ms": avg_main_ms,
+                         "algorithmic_bytes_per_launch": b_alg,
+                         "score_phase_ms": avg_score_ms, "score_phase_GBps": b_alg / (avg_score_ms * 1e-3) / 1e9 if avg_score_ms > 0 else 0.0},
             "phases_ms_per_step": {"prefix": prefix_ms / args.steps, "score": score_ms / args.steps,
+                                   "score_main_kernel": acc["main"] / args.steps, "score_lds_reduce": acc["reduce"] / args.steps,
                                    "compact": compact_ms / args.steps, "device_total": total_ms / args.steps,
                                    "db_merge": acc["merge"] / args.steps},
             "setup_s": {"synth_and_upload": t_gen},

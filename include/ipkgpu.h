@@ -46,7 +46,10 @@ enum {
     IPKGPU_T_PREFIX = 1,        /* prefix-of-column-maxima kernel  (matrix::preprocess) */
     IPKGPU_T_SCORE = 2,         /* scoring + max-reduce kernels (DCLA + put), summed over batches */
     IPKGPU_T_COMPACT = 3,       /* table -> sorted (key, score) compaction kernels */
-    IPKGPU_T_SCORE_LAUNCHES = 4 /* number of scoring-kernel launches the IPKGPU_T_SCORE sum covers */
+    IPKGPU_T_SCORE_LAUNCHES = 4,/* number of scoring passes (batches of groups) the sums cover */
+    IPKGPU_T_SCORE_MAIN = 5,    /* the dominant kernel alone: list building + pair emission (score_stream_kernel /
+                                   score_tiles_kernel), summed over batches */
+    IPKGPU_T_SCORE_REDUCE = 6   /* stream variant: per-bucket LDS max-reduce (reduce_buckets_kernel) */
 };
 
 /* ---- context ------------------------------------------------------------------------- */

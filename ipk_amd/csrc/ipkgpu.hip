@@ -57,6 +57,7 @@ struct ipkgpu_ctx {
     DevBuf table, best, ovfq, counts, offsets, goff, idx, branch, scan_sums, scan_boff, tmp_a, tmp_b, tmp_c;
     DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
+    double acc_main_ms = 0, acc_reduce_ms = 0;   // dominant scoring kernel / LDS reduce pass of the current call
     void* small = nullptr;            // emitted (u64) @0, ovf_count (u32) @16
     int num_cu = 256;
 };
@@ -72,7 +73,7 @@ struct ipkgpu_result {
     std::vector<uint32_t> h_keys;
     std::vector<float> h_scores;
     bool h_keys_ok = false, h_scores_ok = false;
-    double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0;
+    double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0, t_main = 0, t_reduce = 0;
     int score_launches = 0;
 };
 
@@ -84,7 +85,7 @@ struct ipkgpu_parts {
     uint2* d_entries = nullptr;               // owner-major, key-major, group order: (branch, score bits)
     std::vector<uint64_t> owner_off;          // [n_owners + 1] entry offsets
     uint64_t emitted = 0;
-    double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0;
+    double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0, t_main = 0, t_reduce = 0;
     int score_launches = 0;
 };
 
@@ -522,7 +523,13 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const bool use_stream = NBK != 0 && NBK <= 1024 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
     if (!use_stream) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->table.p, 0, (size_t)gb * pl.table_size * 4, ctx->stream));
-        return dispatch_score(ctx, pl.sigma, pl.k, p);
+        Stopwatch sw(ctx->stream);
+        const int a = sw.mark();
+        RC_TRY(dispatch_score(ctx, pl.sigma, pl.k, p));
+        const int b = sw.mark();
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->acc_main_ms += sw.ms(a, b);
+        return IPKGPU_OK;
     }
 
     // ---- stream variant: pass 1 (append pairs) -> chunk index -> pass 2 (LDS reduce) -> big-list windows
@@ -579,7 +586,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         sp.desc = ctx->desc.as<unsigned long long>(); sp.pool_ovf = d_pool_ovf;
         sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count;
         sp.flags = ctx->opt_variant == 0 ? 0u : (uint32_t)(ctx->opt_flags);
+        Stopwatch sw(ctx->stream);
+        const int ev_a = sw.mark();
         RC_TRY(dispatch_stream_pass1(ctx, pl.sigma, pl.k, sp, n_wg));
+        const int ev_b = sw.mark();
         uint32_t h[2] = {0, 0};
         HIP_TRY(ctx, hipMemcpyAsync(h, d_pool_next, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -607,10 +617,15 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
                                ctx->clist.as<uint32_t>());
             HIP_TRY(ctx, hipGetLastError());
         }
+        const int ev_c = sw.mark();
         RC_TRY(dispatch_stream_pass2(ctx, pl.sigma, pl.k, (uint32_t)n_gb, pl.table_size, ctx->table.as<uint32_t>()));
+        const int ev_d = sw.mark();
         // windows whose half lists overflowed the fast path: big-list kernel, max-reduced into the finished tables
         RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
         if (windows) ctx->pairs_per_window = (double)n_used * CH / (double)windows;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->acc_main_ms += sw.ms(ev_a, ev_b);
+        ctx->acc_reduce_ms += sw.ms(ev_c, ev_d);
         return IPKGPU_OK;
     }
     return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool could not be sized");
@@ -672,6 +687,7 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
     RC_TRY(ensure(ctx, ctx->offsets, (size_t)(pl.gpb * cpg + 1) * 8));
     RC_TRY(ensure(ctx, ctx->goff, (size_t)(pl.gpb + 1) * 8));
 
+    ctx->acc_main_ms = ctx->acc_reduce_ms = 0;
     Stopwatch sw(ctx->stream);
     const int t_begin = sw.mark();
     RC_TRY(run_prefix(ctx, pl, logp_dev));
@@ -731,6 +747,7 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
     res->t_total = sw.ms(t_begin, t_end);
     res->t_prefix = sw.ms(t_begin, t_pre);
     for (auto& pr : ev_score) res->t_score += sw.ms(pr.first, pr.second);
+    res->t_main = ctx->acc_main_ms; res->t_reduce = ctx->acc_reduce_ms;
     for (auto& pr : ev_compact) res->t_compact += sw.ms(pr.first, pr.second);
     guard.r = nullptr;
     *out = res;
@@ -799,6 +816,8 @@ double ipkgpu_result_time_ms(const ipkgpu_result* r, int which)
         case IPKGPU_T_SCORE: return r->t_score;
         case IPKGPU_T_COMPACT: return r->t_compact;
         case IPKGPU_T_SCORE_LAUNCHES: return (double)r->score_launches;
+        case IPKGPU_T_SCORE_MAIN: return r->t_main;
+        case IPKGPU_T_SCORE_REDUCE: return r->t_reduce;
     }
     return 0;
 }
@@ -908,6 +927,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     HIP_TRY(ctx, hipMemcpyAsync(ctx->branch.p, pl.group_ids.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
+    ctx->acc_main_ms = ctx->acc_reduce_ms = 0;
     Stopwatch sw(ctx->stream);
     const int t_begin = sw.mark();
     RC_TRY(run_prefix(ctx, pl, logp_dev));
@@ -1000,6 +1020,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     parts->t_total = sw.ms(t_begin, t_end);
     parts->t_prefix = sw.ms(t_begin, t_pre);
     for (auto& pr : ev_score) parts->t_score += sw.ms(pr.first, pr.second);
+    parts->t_main = ctx->acc_main_ms; parts->t_reduce = ctx->acc_reduce_ms;
     for (auto& pr : ev_compact) parts->t_compact += sw.ms(pr.first, pr.second);
     guard.r = nullptr;
     *out = parts;
@@ -1021,6 +1042,8 @@ double ipkgpu_parts_time_ms(const ipkgpu_parts* p, int which)
         case IPKGPU_T_SCORE: return p->t_score;
         case IPKGPU_T_COMPACT: return p->t_compact;
         case IPKGPU_T_SCORE_LAUNCHES: return (double)p->score_launches;
+        case IPKGPU_T_SCORE_MAIN: return p->t_main;
+        case IPKGPU_T_SCORE_REDUCE: return p->t_reduce;
     }
     return 0;
 }

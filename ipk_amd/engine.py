@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libipkgpu.so")
 _lib = None
 
-T_TOTAL, T_PREFIX, T_SCORE, T_COMPACT, T_SCORE_LAUNCHES = range(5)
+T_TOTAL, T_PREFIX, T_SCORE, T_COMPACT, T_SCORE_LAUNCHES, T_SCORE_MAIN, T_SCORE_REDUCE = range(7)
 
 # every symbol include/ipkgpu.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
