@@ -58,6 +58,11 @@ struct ipkgpu_ctx {
     DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
     double acc_main_ms = 0, acc_reduce_ms = 0;   // dominant scoring kernel / LDS reduce pass of the current call
+    // caching allocator for result buffers: hipMalloc/hipFree of multi-GB blocks costs 10-100 ms, so
+    // released result buffers are kept (bounded) and handed out again to the next call
+    std::vector<std::pair<void*, size_t>> free_blocks;
+    std::unordered_map<void*, size_t> live_blocks;
+    size_t cached_bytes = 0, cache_limit = 0;
     void* small = nullptr;            // emitted (u64) @0, ovf_count (u32) @16
     int num_cu = 256;
 };
@@ -133,6 +138,44 @@ static int ensure(ipkgpu_ctx* ctx, DevBuf& b, size_t need)
     return IPKGPU_OK;
 }
 
+
+// ---- caching device allocator for result buffers ---------------------------------------------------
+static hipError_t ctx_alloc(ipkgpu_ctx* ctx, void** out, size_t bytes)
+{
+    bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < ctx->free_blocks.size(); ++i) {
+        const size_t cap = ctx->free_blocks[i].second;
+        if (cap >= bytes && cap <= bytes + bytes / 2 + (1 << 20) && (best == (size_t)-1 || cap < ctx->free_blocks[best].second)) best = i;
+    }
+    if (best != (size_t)-1) {
+        *out = ctx->free_blocks[best].first;
+        ctx->live_blocks[*out] = ctx->free_blocks[best].second;
+        ctx->cached_bytes -= ctx->free_blocks[best].second;
+        ctx->free_blocks.erase(ctx->free_blocks.begin() + best);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !ctx->free_blocks.empty()) {          // out of memory: drop the cache and retry
+        for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
+        ctx->free_blocks.clear(); ctx->cached_bytes = 0;
+        (void)hipGetLastError();
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) ctx->live_blocks[*out] = bytes;
+    return e;
+}
+static void ctx_release(ipkgpu_ctx* ctx, void* p)
+{
+    if (!p) return;
+    auto it = ctx->live_blocks.find(p);
+    if (it == ctx->live_blocks.end()) { (void)hipFree(p); return; }
+    const size_t cap = it->second;
+    ctx->live_blocks.erase(it);
+    if (ctx->cached_bytes + cap <= ctx->cache_limit) { ctx->free_blocks.push_back({p, cap}); ctx->cached_bytes += cap; }
+    else (void)hipFree(p);
+}
+
 namespace {
 
 // Stream-ordered HIP-event stopwatch; events are destroyed with the object.
@@ -194,7 +237,7 @@ int ipkgpu_create(int device_id, ipkgpu_ctx** out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ctx->workspace_bytes = (int64_t)(free_b / 2);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { ctx->workspace_bytes = (int64_t)(free_b / 2); ctx->cache_limit = free_b / 4; }
     else ctx->workspace_bytes = (int64_t)8 << 30;
     if ((e = hipMalloc(&ctx->small, 64)) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
@@ -214,6 +257,7 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
                       &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
                       &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
     if (ctx->small) (void)hipFree(ctx->small);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -340,8 +384,8 @@ int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* ta
         auto kern = reduce_buckets_kernel<TBL, NT>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(), ctx->desc.as<unsigned long long>(),
-                           ctx->gboff.as<uint64_t>(), ctx->clist.as<uint32_t>(), NB, T, table);
+        hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(),
+                           ctx->gboff.as<uint64_t>(), ctx->clist.as<uint2>(), NB, T, table);
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
     }
@@ -604,7 +648,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         // or lie beyond n_used.
         HIP_TRY(ctx, hipMemsetAsync(ctx->gbcnt.p, 0, n_gb * 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->gbcur.p, 0, n_gb * 4, ctx->stream));
-        RC_TRY(ensure(ctx, ctx->clist, std::max<uint64_t>(n_used, 1) * 4));
+        RC_TRY(ensure(ctx, ctx->clist, std::max<uint64_t>(n_used, 1) * 8));
         if (n_used) {
             hipLaunchKernelGGL(chunk_hist_kernel, dim3((n_used + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->desc.as<unsigned long long>(), n_used, ctx->gbcnt.as<uint32_t>());
@@ -614,7 +658,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         if (n_used) {
             hipLaunchKernelGGL(chunk_scatter_kernel, dim3((n_used + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->desc.as<unsigned long long>(), n_used, ctx->gboff.as<uint64_t>(), ctx->gbcur.as<uint32_t>(),
-                               ctx->clist.as<uint32_t>());
+                               ctx->clist.as<uint2>());
             HIP_TRY(ctx, hipGetLastError());
         }
         const int ev_c = sw.mark();
@@ -720,16 +764,16 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
             // grow the output (exact when the last batch is reached; doubling across batches)
             const size_t new_cap = (g0 + gb >= n_groups) ? (size_t)new_total : (size_t)std::max<uint64_t>(new_total, 2 * res->cap);
             uint32_t* nk = nullptr; float* ns = nullptr;
-            HIP_TRY(ctx, hipMalloc((void**)&nk, std::max<size_t>(new_cap, 1) * 4));
-            hipError_t e2 = hipMalloc((void**)&ns, std::max<size_t>(new_cap, 1) * 4);
-            if (e2 != hipSuccess) { (void)hipFree(nk); HIP_TRY(ctx, e2); }
+            HIP_TRY(ctx, ctx_alloc(ctx, (void**)&nk, std::max<size_t>(new_cap, 1) * 4));
+            hipError_t e2 = ctx_alloc(ctx, (void**)&ns, std::max<size_t>(new_cap, 1) * 4);
+            if (e2 != hipSuccess) { ctx_release(ctx, nk); HIP_TRY(ctx, e2); }
             if (total_entries) {
                 (void)hipMemcpyAsync(nk, res->d_keys, total_entries * 4, hipMemcpyDeviceToDevice, ctx->stream);
                 (void)hipMemcpyAsync(ns, res->d_scores, total_entries * 4, hipMemcpyDeviceToDevice, ctx->stream);
                 (void)hipStreamSynchronize(ctx->stream);
             }
-            if (res->d_keys) (void)hipFree(res->d_keys);
-            if (res->d_scores) (void)hipFree(res->d_scores);
+            ctx_release(ctx, res->d_keys);
+            ctx_release(ctx, res->d_scores);
             res->d_keys = nk; res->d_scores = ns; res->cap = new_cap;
         }
         if (sigma == 4)
@@ -825,9 +869,7 @@ double ipkgpu_result_time_ms(const ipkgpu_result* r, int which)
 void ipkgpu_result_free(ipkgpu_result* r)
 {
     if (!r) return;
-    if (r->ctx) (void)hipSetDevice(r->ctx->device);
-    if (r->d_keys) (void)hipFree(r->d_keys);
-    if (r->d_scores) (void)hipFree(r->d_scores);
+    if (r->ctx) { (void)hipSetDevice(r->ctx->device); ctx_release(r->ctx, r->d_keys); ctx_release(r->ctx, r->d_scores); }
     delete r;
 }
 
@@ -867,7 +909,7 @@ int merge_sources(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, u
                            ctx->tmp_c.as<uint64_t>() + (size_t)s * (slots + 1), slots + 1, src_base[s]);
     }
     uint2* dst = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&dst, std::max<uint64_t>(n_total, 1) * 8));
+    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&dst, std::max<uint64_t>(n_total, 1) * 8));
     if (slots) {
         hipLaunchKernelGGL(merge_copy_kernel, dim3((uint32_t)((slots + 3) / 4)), dim3(256), 0, ctx->stream, counts, S, slots,
                            ctx->tmp_c.as<uint64_t>(), src, ctx->tmp_b.as<uint64_t>(), dst);
@@ -882,8 +924,8 @@ int merge_sources(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, u
         uint64_t n_keys = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&n_keys, ctx->offsets.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMalloc((void**)&db->d_keys, std::max<uint64_t>(n_keys, 1) * 4));
-        HIP_TRY(ctx, hipMalloc((void**)&db->d_key_off, (n_keys + 1) * 8));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_keys, std::max<uint64_t>(n_keys, 1) * 4));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_key_off, (n_keys + 1) * 8));
         const uint32_t nbk = (uint32_t)((slots + 1 + 255) / 256);
         if (sigma == 4)
             hipLaunchKernelGGL(merge_write_keys_kernel<4>, dim3(nbk), dim3(256), 0, ctx->stream, total_out, ctx->offsets.as<uint64_t>(),
@@ -937,7 +979,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
 
     struct Batch { uint32_t* counts = nullptr; uint2* entries = nullptr; std::vector<uint64_t> owner_off; };
     std::vector<Batch> batches;
-    auto free_batches = [&]() { for (auto& b : batches) { if (b.counts) (void)hipFree(b.counts); if (b.entries) (void)hipFree(b.entries); } batches.clear(); };
+    auto free_batches = [&]() { for (auto& b : batches) { ctx_release(ctx, b.counts); ctx_release(ctx, b.entries); } batches.clear(); };
     struct BGuard { decltype(free_batches)& f; ~BGuard() { f(); } } bguard{free_batches};
 
     const uint64_t n_slots_all = (uint64_t)P * slots;
@@ -951,7 +993,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
 
         batches.emplace_back();
         Batch& b = batches.back();
-        HIP_TRY(ctx, hipMalloc((void**)&b.counts, n_slots_all * 4));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.counts, n_slots_all * 4));
         HIP_TRY(ctx, hipMemsetAsync(b.counts, 0, n_slots_all * 4, ctx->stream));
         hipLaunchKernelGGL(km_count_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
                            ctx->table.as<uint32_t>(), T, gb, P, slots, b.counts);
@@ -966,7 +1008,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         b.owner_off.resize((size_t)P + 1);
         HIP_TRY(ctx, hipMemcpyAsync(b.owner_off.data(), ctx->goff.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMalloc((void**)&b.entries, std::max<uint64_t>(b.owner_off[P], 1) * 8));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.entries, std::max<uint64_t>(b.owner_off[P], 1) * 8));
         hipLaunchKernelGGL(km_write_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
                            ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
                            ctx->offsets.as<uint64_t>(), b.entries);
@@ -982,12 +1024,12 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         // several batches of groups: per owner, merge the batches (sources in batch = group order)
         const int m0 = sw.mark();
         const uint32_t S = (uint32_t)batches.size();
-        HIP_TRY(ctx, hipMalloc((void**)&parts->d_counts, n_slots_all * 4));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&parts->d_counts, n_slots_all * 4));
         uint64_t grand = 0;
         for (auto& b : batches) grand += b.owner_off[P];
-        HIP_TRY(ctx, hipMalloc((void**)&parts->d_entries, std::max<uint64_t>(grand, 1) * 8));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&parts->d_entries, std::max<uint64_t>(grand, 1) * 8));
         uint32_t* cnt_rows = nullptr;      // [S][slots] of the current owner
-        HIP_TRY(ctx, hipMalloc((void**)&cnt_rows, (size_t)S * slots * 4));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&cnt_rows, (size_t)S * slots * 4));
         uint2* src_cat = nullptr;          // sources of the current owner, concatenated
         uint64_t done = 0;
         int rc = IPKGPU_OK;
@@ -995,7 +1037,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
             std::vector<uint64_t> base(S);
             uint64_t n_o = 0;
             for (uint32_t s = 0; s < S; ++s) { base[s] = n_o; n_o += batches[s].owner_off[o + 1] - batches[s].owner_off[o]; }
-            if (hipMalloc((void**)&src_cat, std::max<uint64_t>(n_o, 1) * 8) != hipSuccess) { rc = fail(ctx, IPKGPU_ERR_NOMEM, "out of device memory in batch merge"); break; }
+            if (ctx_alloc(ctx, (void**)&src_cat, std::max<uint64_t>(n_o, 1) * 8) != hipSuccess) { rc = fail(ctx, IPKGPU_ERR_NOMEM, "out of device memory in batch merge"); break; }
             for (uint32_t s = 0; s < S; ++s) {
                 (void)hipMemcpyAsync(cnt_rows + (size_t)s * slots, batches[s].counts + (size_t)o * slots, slots * 4, hipMemcpyDeviceToDevice, ctx->stream);
                 const uint64_t n_s = batches[s].owner_off[o + 1] - batches[s].owner_off[o];
@@ -1008,10 +1050,10 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
                 (void)hipStreamSynchronize(ctx->stream);
                 parts->owner_off[o] = done; done += n_total; parts->owner_off[o + 1] = done;
             }
-            if (dst) (void)hipFree(dst);
-            (void)hipFree(src_cat); src_cat = nullptr;
+            ctx_release(ctx, dst);
+            ctx_release(ctx, src_cat); src_cat = nullptr;
         }
-        (void)hipFree(cnt_rows);
+        ctx_release(ctx, cnt_rows);
         if (rc) return rc;
         ev_compact.push_back({m0, sw.mark()});
     }
@@ -1050,9 +1092,7 @@ double ipkgpu_parts_time_ms(const ipkgpu_parts* p, int which)
 void ipkgpu_parts_free(ipkgpu_parts* p)
 {
     if (!p) return;
-    if (p->ctx) (void)hipSetDevice(p->ctx->device);
-    if (p->d_counts) (void)hipFree(p->d_counts);
-    if (p->d_entries) (void)hipFree(p->d_entries);
+    if (p->ctx) { (void)hipSetDevice(p->ctx->device); ctx_release(p->ctx, p->d_counts); ctx_release(p->ctx, p->d_entries); }
     delete p;
 }
 
@@ -1116,8 +1156,8 @@ int ipkgpu_db_from_parts(ipkgpu_ctx* ctx, ipkgpu_parts* parts, uint32_t sigma, u
     uint64_t n_keys = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&n_keys, ctx->offsets.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMalloc((void**)&db->d_keys, std::max<uint64_t>(n_keys, 1) * 4));
-    HIP_TRY(ctx, hipMalloc((void**)&db->d_key_off, (n_keys + 1) * 8));
+    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_keys, std::max<uint64_t>(n_keys, 1) * 4));
+    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_key_off, (n_keys + 1) * 8));
     const uint32_t nbk = (uint32_t)((slots + 1 + 255) / 256);
     if (sigma == 4)
         hipLaunchKernelGGL(merge_write_keys_kernel<4>, dim3(nbk), dim3(256), 0, ctx->stream, ctx->counts.as<uint32_t>(),
@@ -1165,10 +1205,7 @@ const uint32_t* ipkgpu_db_entries(ipkgpu_db* d) { return d && db_to_host(d) ? d-
 void ipkgpu_db_free(ipkgpu_db* d)
 {
     if (!d) return;
-    if (d->ctx) (void)hipSetDevice(d->ctx->device);
-    if (d->d_keys) (void)hipFree(d->d_keys);
-    if (d->d_key_off) (void)hipFree(d->d_key_off);
-    if (d->d_entries) (void)hipFree(d->d_entries);
+    if (d->ctx) { (void)hipSetDevice(d->ctx->device); ctx_release(d->ctx, d->d_keys); ctx_release(d->ctx, d->d_key_off); ctx_release(d->ctx, d->d_entries); }
     delete d;
 }
 

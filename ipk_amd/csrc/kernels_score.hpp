@@ -278,30 +278,34 @@ __global__ __launch_bounds__(NW * 64) void score_stream_kernel(StreamParams p)
                 continue;
             }
             if (nL == 0 || nR == 0) continue;
+            if (p.flags & 4u) { emitted += nL + nR; continue; }                 // diagnostics: list building only
             constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
             uint32_t cnt = 0;
             for_each_pair(L, nL, R, nR, [&](bool valid, uint2 a, uint2 b) {
                 const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
                 const bool pass = valid && (s > p.eps);                            // :91
+                const uint64_t pm = __ballot(pass);
+                if (pm == 0) return;
+                const uint32_t n = (uint32_t)__popcll(pm);
+                cnt += n;
+                if (p.flags & 2u) return;
                 const uint32_t idx = a.x * mulR + b.x;
                 const uint32_t bk = pass ? idx / TBL : 0u;
-                uint32_t slot = 0, cb = CHUNK_NONE;
-                if (pass && !(p.flags & 2u)) { slot = atomicAdd(&cfill[bk], 1u); cb = cbase[bk]; }
                 const uint2 pr = make_uint2(idx, __float_as_uint(s));
+                uint32_t slot = 0, cb = CHUNK_NONE;
+                if (pass) { slot = atomicAdd(&cfill[bk], 1u); cb = cbase[bk]; }
                 if (pass && slot < CH && cb != CHUNK_NONE && !(p.flags & 1u)) p.pool[(size_t)cb * CH + slot] = pr;
-                const uint64_t pm = __ballot(pass);
-                cnt += (uint32_t)__popcll(pm);
                 uint64_t ovf = __ballot(pass && slot >= CH);
                 while (ovf) {                                   // a bucket's chunk filled up: open a new one
                     const uint32_t l0 = (uint32_t)__ffsll((long long)ovf) - 1u;
-                    const uint32_t bb = __shfl(bk, (int)l0);
+                    const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bk, (int)l0);
                     const uint64_t m = __ballot(pass && slot >= CH && bk == bb);
                     // chunk ids are drawn ALLOC_BATCH at a time: one returning atomic on a single word
                     // saturates at ~88 per microsecond chip-wide, far below one per 256 pairs
                     if (chunk_next == chunk_end) {
                         uint32_t base = 0;
                         if (lane == 0) base = atomicAdd(p.pool_next, ALLOC_BATCH);
-                        chunk_next = __shfl(base, 0);
+                        chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                         chunk_end = chunk_next + ALLOC_BATCH;
                     }
                     uint32_t nid = chunk_next++;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NW * 64) void score_stream_kernel(StreamParams p)
                         cfill[bb] = cfill[bb] - CH;
                     }
                     wave_lds_sync();
-                    if (((m >> lane) & 1ull) && nid != CHUNK_NONE) p.pool[(size_t)nid * CH + (slot - CH)] = pr;
+                    if (((m >> lane) & 1ull) && nid != CHUNK_NONE && !(p.flags & 1u)) p.pool[(size_t)nid * CH + (slot - CH)] = pr;
                     ovf &= ~m;
                 }
             });
@@ -343,45 +347,68 @@ __global__ __launch_bounds__(256) void chunk_hist_kernel(const unsigned long lon
 }
 __global__ __launch_bounds__(256) void chunk_scatter_kernel(const unsigned long long* __restrict__ desc, uint32_t n,
                                                             const uint64_t* __restrict__ off, uint32_t* __restrict__ cur,
-                                                            uint32_t* __restrict__ list)
+                                                            uint2* __restrict__ list)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned long long d = desc[i];
     if ((uint32_t)d == 0u) return;
     const uint32_t gb = (uint32_t)(d >> 32);
-    list[off[gb] + atomicAdd(&cur[gb], 1u)] = i;
+    list[off[gb] + atomicAdd(&cur[gb], 1u)] = make_uint2(i, (uint32_t)d);      // (chunk id, pair count)
 }
 
-// pass 2: one workgroup per (group, bucket): LDS max-reduce of the bucket's chunks, then the table slice
+// pass 2: one workgroup per (group, bucket): LDS max-reduce of the bucket's chunks, then the table slice.
+// Each wave takes two chunks per trip and issues all of their pair loads (8 x 512 B) before the first
+// LDS atomic, so ~4 KiB per wave are in flight.
 template <uint32_t TBL, int NT>
 __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restrict__ pool,
-                                                           const unsigned long long* __restrict__ desc,
-                                                           const uint64_t* __restrict__ off, const uint32_t* __restrict__ list,
+                                                           const uint64_t* __restrict__ off, const uint2* __restrict__ list,
                                                            uint32_t NB, uint64_t T, uint32_t* __restrict__ table)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    constexpr uint32_t NWV = NT / 64;
     const uint32_t gb = blockIdx.x;
     const uint32_t g = gb / NB, b = gb - g * NB;
     const uint64_t key0 = (uint64_t)b * TBL;
     const uint32_t nslots = (uint32_t)min((uint64_t)TBL, T - key0);
-    for (uint32_t i = threadIdx.x; i < TBL; i += NT) tab[i] = 0u;
-    __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint64_t c0 = off[gb], c1 = off[gb + 1];
-    for (uint64_t ci = c0 + wave; ci < c1; ci += NT / 64) {
-        const uint32_t id = list[ci];
-        const uint32_t n = (uint32_t)desc[id];
-        const uint2* src = pool + (size_t)id * CH;
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint2 pr = src[i];
-            atomicMax(&tab[pr.x - (uint32_t)key0], enc_score_bits(pr.y));
+    // first chunk descriptors are requested before the table is cleared
+    uint64_t ci = c0 + wave;
+    uint2 e0 = make_uint2(0, 0), e1 = make_uint2(0, 0);
+    if (ci < c1) e0 = list[ci];
+    if (ci + NWV < c1) e1 = list[ci + NWV];
+    for (uint32_t i = threadIdx.x; i < TBL / 4; i += NT) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t k0 = (uint32_t)key0;
+    while (ci < c1) {
+        const uint2* s0 = pool + (size_t)e0.x * CH;
+        const uint2* s1 = pool + (size_t)e1.x * CH;
+        const uint32_t n0 = e0.y, n1 = (ci + NWV < c1) ? e1.y : 0u;
+        uint2 v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = make_uint2(0, 0); v[4 + j] = make_uint2(0, 0);
+            if (lane + 64 * j < n0) v[j] = s0[lane + 64 * j];
+            if (lane + 64 * j < n1) v[4 + j] = s1[lane + 64 * j];
+        }
+        ci += 2 * NWV;
+        if (ci < c1) e0 = list[ci];
+        if (ci + NWV < c1) e1 = list[ci + NWV];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (lane + 64 * j < n0) atomicMax(&tab[v[j].x - k0], enc_score_bits(v[j].y));
+            if (lane + 64 * j < n1) atomicMax(&tab[v[4 + j].x - k0], enc_score_bits(v[4 + j].y));
         }
     }
     __syncthreads();
     uint32_t* dst = table + (size_t)g * T + key0;
-    for (uint32_t i = threadIdx.x; i < nslots; i += NT) dst[i] = tab[i];
+    if ((nslots & 3u) == 0 && ((((size_t)g * T + key0) & 3u) == 0)) {
+        for (uint32_t i = threadIdx.x; i < nslots / 4; i += NT) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<uint4*>(tab)[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < nslots; i += NT) dst[i] = tab[i];
+    }
 }
 
 }  // namespace ipkgpu
