@@ -287,7 +287,7 @@ constexpr int NW = 4;    // wavefronts per workgroup
 
 template <int SIGMA, int K> constexpr int fast_cap()
 {
-    if (SIGMA == 4) return K <= 10 ? 256 : 512;
+    if (SIGMA == 4) return K <= 10 ? 192 : 512;
     return 512;
 }
 
@@ -361,7 +361,7 @@ int launch_stream_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
         constexpr int CAP = fast_cap<SIGMA, K>();
         constexpr uint32_t T = ipow(SIGMA, K);
         constexpr uint32_t NB = (T + TBL - 1) / TBL;
-        constexpr size_t lds = TileGeo<SIGMA, K, TW>::HEAD_BYTES + (size_t)NW * wave_scratch_entries<SIGMA, K, CAP>() * 8 + (size_t)NW * 2 * NB * 4;
+        constexpr size_t lds = TileGeo<SIGMA, K, TW>::HEAD_BYTES + (size_t)NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NW * 2 * NB * SUB * 4;
         static_assert(lds <= 160 * 1024, "stream pass-1 LDS budget");
         auto kern = score_stream_kernel<SIGMA, K, CAP, TW, NW, TBL>;
         if (lds > 64 * 1024)
@@ -604,10 +604,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     (void)hipMemGetInfo(&free_b, &total_b);
     const uint64_t max_chunks = std::min<uint64_t>(0xFFFFFFF0ull, (uint64_t)(free_b + ctx->pool.cap + ctx->desc.cap) * 9 / 10 / (CH * 8 + 8));
     double ppw = ctx->pairs_per_window > 0 ? ctx->pairs_per_window * 1.25 : 256.0;
-    uint64_t want = (uint64_t)((double)windows * ppw / CH) + 2 * n_waves * NBK + n_waves * ALLOC_BATCH + 1024;
+    uint64_t want = (uint64_t)((double)windows * ppw / CH) + 2 * n_waves * NBK * SUB + n_waves * ALLOC_BATCH + 1024;
     for (int attempt = 0; attempt < 6; ++attempt) {
         uint64_t cap = std::min<uint64_t>(want, max_chunks);
-        if (cap < 2 * n_waves * NBK) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool does not fit device memory (lower workspace_bytes)");
+        if (cap < n_waves * NBK * SUB) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool does not fit device memory (lower workspace_bytes)");
         RC_TRY(ensure(ctx, ctx->pool, cap * CH * 8));
         RC_TRY(ensure(ctx, ctx->desc, cap * 8));
         cap = std::min<uint64_t>(ctx->pool.cap / (CH * 8), ctx->desc.cap / 8);

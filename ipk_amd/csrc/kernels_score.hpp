@@ -203,6 +203,7 @@ __global__ __launch_bounds__(64) void score_overflow_kernel(ScoreParams p)
 constexpr uint32_t CH = 256;                 // pairs per chunk (2 KiB)
 constexpr uint32_t CHUNK_NONE = 0xFFFFFFFFu;
 constexpr uint32_t ALLOC_BATCH = 32;         // chunk ids a wavefront draws per global atomic
+constexpr uint32_t SUB = 1;                  // open chunks per (wave, bucket); >1 spreads a bucket over lane-interleaved chunks
 
 struct StreamParams {
     const float* logp;
@@ -222,6 +223,169 @@ struct StreamParams {
     uint32_t flags;                // diagnostics: bit 0 = skip the pool stores, bit 1 = skip the append bookkeeping too
 };
 
+// M with floor(t / n) == (t * M) >> 16 for 0 <= t < 128, 1 <= n <= 64   (M = ceil(65536 / n))
+__device__ __constant__ uint32_t RCP16[65] = {
+    0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096,
+    3856, 3641, 3450, 3277, 3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2048,
+    1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599, 1561, 1525, 1490, 1457, 1425, 1395, 1366,
+    1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041, 1024};
+
+// Both halves of the window are joins of two small nodes (sigma^h <= 64 each): DNA k = 8..12.
+template <int SIGMA, int K>
+struct HalvesDD {
+    static constexpr int HL = K / 2, HR = K - K / 2;
+    static constexpr int LA = HL / 2, LB = HL - LA, RA = HR / 2, RB = HR - RA;
+    static constexpr bool OK = ipow(SIGMA, HL) > 64 && ipow(SIGMA, LB) <= 64 && ipow(SIGMA, RB) <= 64;
+    static constexpr uint32_t FLA = ipow(SIGMA, LA), FLB = ipow(SIGMA, LB), FRA = ipow(SIGMA, RA), FRB = ipow(SIGMA, RB);
+};
+template <int SIGMA, int K, int CAP>
+constexpr uint32_t stream_wave_scratch()
+{
+    using D = HalvesDD<SIGMA, K>;
+    if constexpr (D::OK)
+        return Geo<SIGMA, D::HL, CAP>::CAPH + Geo<SIGMA, D::HR, CAP>::CAPH + D::FLA + D::FLB + D::FRA + D::FRB;   // + the four child lists
+    else
+        return wave_scratch_entries<SIGMA, K, CAP>();
+}
+
+// List building with the four child nodes evaluated back to back (all their LDS reads in flight
+// together) and both half joins sharing one step when they fit 64 candidates each.  Same sets and
+// same arithmetic as Node<>::build; only the order of independent work differs.
+template <int SIGMA, int K, int CAP>
+__device__ __forceinline__ bool build_halves_dd(const WinCtx& c, float eps, uint2* scratch,
+                                                const uint2*& Lp, uint32_t& nL, const uint2*& Rp, uint32_t& nR)
+{
+    using D = HalvesDD<SIGMA, K>;
+    constexpr int HL = D::HL, HR = D::HR, LA = D::LA, LB = D::LB, RA = D::RA, RB = D::RB;
+    using GL = Geo<SIGMA, HL, CAP>;
+    using GR = Geo<SIGMA, HR, CAP>;
+    const uint32_t lane = lane_id();
+    const float* bs = c.best + c.w;
+    const float eps_l = eps - (bs[K] - bs[HL]);                      // pk_compute.cpp:54 at (0, K)
+    const float eps_r = eps - (bs[HL] - bs[0]);                      // :55
+    const float eps_la = eps_l - (bs[HL] - bs[LA]);                  // :54 at (0, HL)
+    const float eps_lb = eps_l - (bs[LA] - bs[0]);                   // :55
+    const float eps_ra = eps_r - (bs[K] - bs[HL + RA]);              // :54 at (HL, HR)
+    const float eps_rb = eps_r - (bs[HL + RA] - bs[HL]);             // :55
+    uint2* lp = scratch;
+    uint2* rp = lp + GL::CAPH;
+    uint2* la = rp + GR::CAPH;
+    uint2* lb = la + D::FLA;
+    uint2* ra = lb + D::FLB;
+    uint2* rb = ra + D::FRA;
+    Lp = lp; Rp = rp; nL = 0; nR = 0;
+
+    float sla = 0.f, slb = 0.f, sra = 0.f, srb = 0.f;
+    bool pla = false, plb = false, pra = false, prb = false;
+    if (lane < D::FLA) pla = Direct<SIGMA, 0, LA>::eval(c, eps_la, lane, sla);
+    if (lane < D::FLB) plb = Direct<SIGMA, LA, LB>::eval(c, eps_lb, lane, slb);
+    if (lane < D::FRA) pra = Direct<SIGMA, HL, RA>::eval(c, eps_ra, lane, sra);
+    if (lane < D::FRB) prb = Direct<SIGMA, HL + RA, RB>::eval(c, eps_rb, lane, srb);
+    const uint64_t mla = __ballot(pla), mlb = __ballot(plb), mra = __ballot(pra), mrb = __ballot(prb);
+    if (mla == 0 || mlb == 0 || mra == 0 || mrb == 0) return true;         // an empty half: nothing survives
+    if (pla) la[mbcnt(mla)] = make_uint2(lane, __float_as_uint(sla));
+    if (plb) lb[mbcnt(mlb)] = make_uint2(lane, __float_as_uint(slb));
+    if (pra) ra[mbcnt(mra)] = make_uint2(lane, __float_as_uint(sra));
+    if (prb) rb[mbcnt(mrb)] = make_uint2(lane, __float_as_uint(srb));
+    const uint32_t nla = (uint32_t)__popcll(mla), nlb = (uint32_t)__popcll(mlb);
+    const uint32_t nra = (uint32_t)__popcll(mra), nrb = (uint32_t)__popcll(mrb);
+    wave_lds_sync();
+    const uint32_t tl = nla * nlb, tr = nra * nrb;
+    uint32_t cl, cr;
+    if (tl <= 64 && tr <= 64) {
+        // one step for both halves
+        const uint32_t il = (lane * RCP16[nlb]) >> 16, jl = lane - il * nlb;
+        const uint32_t ir = (lane * RCP16[nrb]) >> 16, jr = lane - ir * nrb;
+        uint2 a0 = make_uint2(0, 0), b0 = a0, a1 = a0, b1 = a0;
+        if (lane < tl) { a0 = la[il]; b0 = lb[jl]; }
+        if (lane < tr) { a1 = ra[ir]; b1 = rb[jr]; }
+        const float s0 = __uint_as_float(a0.y) + __uint_as_float(b0.y);          // :90
+        const float s1 = __uint_as_float(a1.y) + __uint_as_float(b1.y);
+        const bool p0 = (lane < tl) && (s0 > eps_l);                             // :91
+        const bool p1 = (lane < tr) && (s1 > eps_r);
+        const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
+        if (p0) lp[mbcnt(m0)] = make_uint2(a0.x * D::FLB + b0.x, __float_as_uint(s0));
+        if (p1) rp[mbcnt(m1)] = make_uint2(a1.x * D::FRB + b1.x, __float_as_uint(s1));
+        cl = (uint32_t)__popcll(m0); cr = (uint32_t)__popcll(m1);
+    } else {
+        cl = join_to_list(la, nla, lb, nlb, eps_l, D::FLB, lp, GL::CAPH);
+        if (cl == LIST_OVERFLOW) return false;
+        if (cl == 0) return true;
+        cr = join_to_list(ra, nra, rb, nrb, eps_r, D::FRB, rp, GR::CAPH);
+        if (cr == LIST_OVERFLOW) return false;
+    }
+    nL = cl; nR = cr;
+    wave_lds_sync();
+    return true;
+}
+
+// Per-wave appender of surviving (code, score) pairs to the pair pool: one open chunk per key bucket.
+template <uint32_t TBL, uint32_t NB>
+struct Appender {
+    const StreamParams& p;
+    uint32_t* cbase;
+    uint32_t* cfill;
+    uint32_t g;
+    uint32_t chunk_next = 0, chunk_end = 0;            // this wave's private range of free chunk ids
+
+    // The chunk of state slot `bb` (= bucket * SUB + sub) is full: close it, open a new one, return its id
+    // (CHUNK_NONE if the pool ran out).
+    __device__ __forceinline__ uint32_t roll(uint32_t bb)
+    {
+        const uint32_t lane = lane_id();
+        // chunk ids are drawn ALLOC_BATCH at a time: one returning atomic on a single word saturates at
+        // ~88 per microsecond chip-wide, far below one per 256 pairs
+        if (chunk_next == chunk_end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(p.pool_next, ALLOC_BATCH);
+            chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            chunk_end = chunk_next + ALLOC_BATCH;
+        }
+        uint32_t nid = chunk_next++;
+        if (nid >= p.pool_cap) { if (lane == 0) atomicOr(p.pool_ovf, 1u); nid = CHUNK_NONE; }
+        wave_lds_sync();
+        const uint32_t old_id = cbase[bb];
+        wave_lds_sync();
+        if (lane == 0) {
+            if (old_id != CHUNK_NONE) p.desc[old_id] = ((unsigned long long)(g * NB + bb / SUB) << 32) | (unsigned long long)CH;
+            cbase[bb] = nid;
+            cfill[bb] = cfill[bb] - CH;
+        }
+        wave_lds_sync();
+        return nid;
+    }
+
+    // Two candidates per lane (two steps of the final join): slots are reserved with LDS atomics, both
+    // reservations in flight together.  (Ballot-ranked variants without same-address atomics were
+    // measured 40-55 % slower: the extra 64-bit lane masks push the kernel into SGPR spilling.)
+    __device__ __forceinline__ void append2(bool pass0, uint32_t idx0, uint32_t sb0, bool pass1, uint32_t idx1, uint32_t sb1)
+    {
+        const uint32_t sub = lane_id() & (SUB - 1);
+        const uint32_t bk0 = pass0 ? (idx0 / TBL) * SUB + sub : 0u, bk1 = pass1 ? (idx1 / TBL) * SUB + sub : 0u;
+        uint32_t slot0 = 0, slot1 = 0, cb0 = CHUNK_NONE, cb1 = CHUNK_NONE;
+        if (pass0) slot0 = atomicAdd(&cfill[bk0], 1u);
+        if (pass1) slot1 = atomicAdd(&cfill[bk1], 1u);
+        if (pass0) cb0 = cbase[bk0];
+        if (pass1) cb1 = cbase[bk1];
+        const bool st = !(p.flags & 1u);
+        if (pass0 && slot0 < CH && cb0 != CHUNK_NONE && st) p.pool[(size_t)cb0 * CH + slot0] = make_uint2(idx0, sb0);
+        if (pass1 && slot1 < CH && cb1 != CHUNK_NONE && st) p.pool[(size_t)cb1 * CH + slot1] = make_uint2(idx1, sb1);
+        const bool o0 = pass0 && slot0 >= CH, o1 = pass1 && slot1 >= CH;
+        uint64_t ovf0 = __ballot(o0), ovf1 = __ballot(o1);
+        while (ovf0 | ovf1) {                           // a bucket's chunk filled up: open a new one
+            uint32_t bb;
+            if (ovf0) bb = (uint32_t)__builtin_amdgcn_readlane((int)bk0, (int)(__ffsll((long long)ovf0) - 1));
+            else      bb = (uint32_t)__builtin_amdgcn_readlane((int)bk1, (int)(__ffsll((long long)ovf1) - 1));
+            const bool h0 = o0 && bk0 == bb, h1 = o1 && bk1 == bb;
+            const uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+            const uint32_t nid = roll(bb);
+            if (h0 && nid != CHUNK_NONE && st) p.pool[(size_t)nid * CH + (slot0 - CH)] = make_uint2(idx0, sb0);
+            if (h1 && nid != CHUNK_NONE && st) p.pool[(size_t)nid * CH + (slot1 - CH)] = make_uint2(idx1, sb1);
+            ovf0 &= ~m0; ovf1 &= ~m1;
+        }
+    }
+};
+
 template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL>
 __global__ __launch_bounds__(NW * 64) void score_stream_kernel(StreamParams p)
 {
@@ -229,11 +393,11 @@ __global__ __launch_bounds__(NW * 64) void score_stream_kernel(StreamParams p)
     using TG = TileGeo<SIGMA, K, TW>;
     constexpr uint32_t T = ipow(SIGMA, K);
     constexpr uint32_t NB = (T + TBL - 1) / TBL;
-    constexpr uint32_t WS = wave_scratch_entries<SIGMA, K, CAP>();
+    constexpr uint32_t WS = stream_wave_scratch<SIGMA, K, CAP>();
     float* cols = reinterpret_cast<float*>(smem);
     float* best = cols + TG::COLS_F;
     uint2* scratch_all = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
-    uint32_t* state_all = reinterpret_cast<uint32_t*>(scratch_all + (size_t)NW * WS);   // per wave: base[NB], fill[NB]
+    uint32_t* state_all = reinterpret_cast<uint32_t*>(scratch_all + (size_t)NW * WS);   // per wave: base[NB*SUB], fill[NB*SUB]
 
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t g = blockIdx.x / p.S, seg = blockIdx.x - g * p.S;
@@ -243,11 +407,12 @@ __global__ __launch_bounds__(NW * 64) void score_stream_kernel(StreamParams p)
     const uint32_t t_hi = (uint32_t)(((uint64_t)total_tiles * (seg + 1)) / p.S);
 
     uint2* scratch = scratch_all + (size_t)wave * WS;
-    uint32_t* cbase = state_all + (size_t)wave * 2 * NB;
-    uint32_t* cfill = cbase + NB;
-    for (uint32_t b = lane; b < NB; b += 64) { cbase[b] = CHUNK_NONE; cfill[b] = CH; }
+    uint32_t* cbase = state_all + (size_t)wave * 2 * NB * SUB;
+    uint32_t* cfill = cbase + NB * SUB;
+    for (uint32_t b = lane; b < NB * SUB; b += 64) { cbase[b] = CHUNK_NONE; cfill[b] = CH; }
+    Appender<TBL, NB> app{p, cbase, cfill, g};
     uint32_t emitted = 0;
-    uint32_t chunk_next = 0, chunk_end = 0;            // this wave's private range of free chunk ids
+    constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
 
     for (uint32_t t = t_lo; t < t_hi; ++t) {
         const uint32_t q = t / p.tiles_per_mat, tile = t - q * p.tiles_per_mat;
@@ -270,7 +435,10 @@ __global__ __launch_bounds__(NW * 64) void score_stream_kernel(StreamParams p)
             const uint2 *L, *R;
             uint32_t nL, nR;
             static_assert(!Geo<SIGMA, K, CAP>::DIRECT, "stream variant needs k with sigma^k > 64");
-            if (!build_halves<SIGMA, K, CAP>(c, p.eps, scratch, L, nL, R, nR)) {
+            bool ok;
+            if constexpr (HalvesDD<SIGMA, K>::OK) ok = build_halves_dd<SIGMA, K, CAP>(c, p.eps, scratch, L, nL, R, nR);
+            else ok = build_halves<SIGMA, K, CAP>(c, p.eps, scratch, L, nL, R, nR);
+            if (!ok) {
                 if (lane == 0) {
                     const uint32_t qi = atomicAdd(p.ovf_count, 1u);
                     p.ovf_queue[qi] = ((unsigned long long)mat << 32) | (unsigned long long)(t0 + w);
@@ -279,59 +447,58 @@ __global__ __launch_bounds__(NW * 64) void score_stream_kernel(StreamParams p)
             }
             if (nL == 0 || nR == 0) continue;
             if (p.flags & 4u) { emitted += nL + nR; continue; }                 // diagnostics: list building only
-            constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
             uint32_t cnt = 0;
-            for_each_pair(L, nL, R, nR, [&](bool valid, uint2 a, uint2 b) {
-                const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
-                const bool pass = valid && (s > p.eps);                            // :91
-                const uint64_t pm = __ballot(pass);
-                if (pm == 0) return;
-                const uint32_t n = (uint32_t)__popcll(pm);
-                cnt += n;
-                if (p.flags & 2u) return;
-                const uint32_t idx = a.x * mulR + b.x;
-                const uint32_t bk = pass ? idx / TBL : 0u;
-                const uint2 pr = make_uint2(idx, __float_as_uint(s));
-                uint32_t slot = 0, cb = CHUNK_NONE;
-                if (pass) { slot = atomicAdd(&cfill[bk], 1u); cb = cbase[bk]; }
-                if (pass && slot < CH && cb != CHUNK_NONE && !(p.flags & 1u)) p.pool[(size_t)cb * CH + slot] = pr;
-                uint64_t ovf = __ballot(pass && slot >= CH);
-                while (ovf) {                                   // a bucket's chunk filled up: open a new one
-                    const uint32_t l0 = (uint32_t)__ffsll((long long)ovf) - 1u;
-                    const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bk, (int)l0);
-                    const uint64_t m = __ballot(pass && slot >= CH && bk == bb);
-                    // chunk ids are drawn ALLOC_BATCH at a time: one returning atomic on a single word
-                    // saturates at ~88 per microsecond chip-wide, far below one per 256 pairs
-                    if (chunk_next == chunk_end) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(p.pool_next, ALLOC_BATCH);
-                        chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        chunk_end = chunk_next + ALLOC_BATCH;
-                    }
-                    uint32_t nid = chunk_next++;
-                    if (nid >= p.pool_cap) { if (lane == 0) atomicOr(p.pool_ovf, 1u); nid = CHUNK_NONE; }
-                    wave_lds_sync();
-                    const uint32_t old_id = cbase[bb];
-                    wave_lds_sync();
-                    if (lane == 0) {
-                        if (old_id != CHUNK_NONE)
-                            p.desc[old_id] = ((unsigned long long)(g * NB + bb) << 32) | (unsigned long long)CH;
-                        cbase[bb] = nid;
-                        cfill[bb] = cfill[bb] - CH;
-                    }
-                    wave_lds_sync();
-                    if (((m >> lane) & 1ull) && nid != CHUNK_NONE && !(p.flags & 1u)) p.pool[(size_t)nid * CH + (slot - CH)] = pr;
-                    ovf &= ~m;
+            if (nR < 64) {
+                // flattened candidate space, two steps (128 candidates) per trip; (i, j) of a candidate
+                // from a scalar (bi, bj) of the step's first candidate plus one multiply-shift per lane
+                const uint32_t total = nL * nR;
+                const uint32_t M = RCP16[nR];
+                const uint32_t q64 = (64u * M) >> 16, r64 = 64u - q64 * nR;
+                uint32_t bi = 0, bj = 0;
+                for (uint32_t base = 0; base < total; base += 128) {
+                    uint32_t bi1 = bi + q64, bj1 = bj + r64;
+                    if (bj1 >= nR) { bj1 -= nR; ++bi1; }
+                    const uint32_t ta = bj + lane, tb = bj1 + lane;
+                    const uint32_t qa = (ta * M) >> 16, qb = (tb * M) >> 16;
+                    const bool va = base + lane < total, vb = base + 64 + lane < total;
+                    uint2 a0 = make_uint2(0, 0), b0 = a0, a1 = a0, b1 = a0;
+                    if (va) { a0 = L[bi + qa]; b0 = R[ta - qa * nR]; }
+                    if (vb) { a1 = L[bi1 + qb]; b1 = R[tb - qb * nR]; }
+                    const float s0 = __uint_as_float(a0.y) + __uint_as_float(b0.y);      // pk_compute.cpp:90
+                    const float s1 = __uint_as_float(a1.y) + __uint_as_float(b1.y);
+                    const bool p0 = va && (s0 > p.eps), p1 = vb && (s1 > p.eps);          // :91
+                    cnt += (uint32_t)__popcll(__ballot(p0)) + (uint32_t)__popcll(__ballot(p1));
+                    if (!(p.flags & 2u))
+                        app.append2(p0, a0.x * mulR + b0.x, __float_as_uint(s0), p1, a1.x * mulR + b1.x, __float_as_uint(s1));
+                    bi = bi1 + q64; bj = bj1 + r64;
+                    if (bj >= nR) { bj -= nR; ++bi; }
                 }
-            });
+            } else {
+                for (uint32_t i = 0; i < nL; ++i) {
+                    const uint2 a = L[i];
+                    for (uint32_t jb = 0; jb < nR; jb += 128) {
+                        const uint32_t ja = jb + lane, jc = jb + 64 + lane;
+                        const bool va = ja < nR, vb = jc < nR;
+                        uint2 b0 = make_uint2(0, 0), b1 = b0;
+                        if (va) b0 = R[ja];
+                        if (vb) b1 = R[jc];
+                        const float s0 = __uint_as_float(a.y) + __uint_as_float(b0.y);
+                        const float s1 = __uint_as_float(a.y) + __uint_as_float(b1.y);
+                        const bool p0 = va && (s0 > p.eps), p1 = vb && (s1 > p.eps);
+                        cnt += (uint32_t)__popcll(__ballot(p0)) + (uint32_t)__popcll(__ballot(p1));
+                        if (!(p.flags & 2u))
+                            app.append2(p0, a.x * mulR + b0.x, __float_as_uint(s0), p1, a.x * mulR + b1.x, __float_as_uint(s1));
+                    }
+                }
+            }
             emitted += cnt;
         }
     }
     // close this wave's open chunks
     wave_lds_sync();
-    for (uint32_t b = lane; b < NB; b += 64) {
+    for (uint32_t b = lane; b < NB * SUB; b += 64) {
         const uint32_t id = cbase[b];
-        if (id != CHUNK_NONE) p.desc[id] = ((unsigned long long)(g * NB + b) << 32) | (unsigned long long)min(cfill[b], CH);
+        if (id != CHUNK_NONE) p.desc[id] = ((unsigned long long)(g * NB + b / SUB) << 32) | (unsigned long long)min(cfill[b], CH);
     }
     if (lane == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
 }
