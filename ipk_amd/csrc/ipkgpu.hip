@@ -319,8 +319,8 @@ int launch_overflow(ipkgpu_ctx* ctx, const ScoreParams& p)
         auto kern = score_overflow_kernel<SIGMA, K>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-        hipLaunchKernelGGL(kern, dim3(ctx->num_cu * per_cu), dim3(64), lds, ctx->stream, p);
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 64)));
+        hipLaunchKernelGGL(kern, dim3(ctx->num_cu * per_cu), dim3(OVF_NW * 64), lds, ctx->stream, p);
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
     }

@@ -156,36 +156,66 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
     if (lane_id() == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
 }
 
-// Big-list path: one wavefront per workgroup with worst-case list capacity (sigma^(k/2) entries per
-// half list), walking the queue of windows the fast path could not hold.  Every wave reaches the
-// loop exit: the queue length is fixed before this kernel starts.
+// Big-list path: windows whose half lists exceed the fast path's capacity.  One workgroup of OVF_NW
+// wavefronts per window with worst-case list capacity (sigma^ceil(k/2) entries per half list): wave 0
+// builds the two half lists, then all waves share the final cross product (it is what is big here:
+// |L| x |R| up to 4096^2) and max-reduce into the group's table with global atomics.  Every wave
+// reaches the loop exit: the queue length is fixed before this kernel starts.
+constexpr int OVF_NW = 8;
+
 template <int SIGMA, int K>
-__global__ __launch_bounds__(64) void score_overflow_kernel(ScoreParams p)
+__global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int CAPF = 1 << 30;
     using TG = TileGeo<SIGMA, K, 1>;
+    __shared__ uint32_t sh_n[2];
     float* cols = reinterpret_cast<float*>(smem);
     float* best = cols + TG::COLS_F;
     uint2* scratch = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
     const uint32_t n = *p.ovf_count;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t emitted = 0;
+    constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
     for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
         const unsigned long long e = p.ovf_queue[q];
         const uint32_t mat = (uint32_t)(e >> 32), start = (uint32_t)e;
+        __syncthreads();                                                       // previous window's lists consumed
         const float* src = p.logp + ((size_t)mat * p.sites + start) * SIGMA;
-        for (uint32_t i = threadIdx.x; i < K * SIGMA; i += 64) cols[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < K * SIGMA; i += OVF_NW * 64) cols[i] = src[i];
         const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + start;
-        for (uint32_t i = threadIdx.x; i <= K; i += 64) best[i] = bsrc[i];
-        wave_lds_sync();
-        WinCtx c{cols, best, 0};
+        for (uint32_t i = threadIdx.x; i <= K; i += OVF_NW * 64) best[i] = bsrc[i];
+        __syncthreads();
         uint32_t* tab = p.table + (size_t)p.mat_slot[mat] * p.table_size;
-        score_window<SIGMA, K, CAPF>(c, p.eps, scratch, tab, emitted);
-        wave_lds_sync();
+        const uint2 *L = scratch, *R = scratch + Geo<SIGMA, K / 2, CAPF>::CAPH;
+        if (wave == 0) {
+            WinCtx c{cols, best, 0};
+            uint32_t nL = 0, nR = 0;
+            build_halves<SIGMA, K, CAPF>(c, p.eps, scratch, L, nL, R, nR);      // cannot overflow at full capacity
+            if (lane == 0) { sh_n[0] = nL; sh_n[1] = nR; }
+        }
+        __syncthreads();
+        const uint32_t nL = sh_n[0], nR = sh_n[1];
+        if (nL == 0 || nR == 0) continue;
+        uint32_t cnt = 0;
+        // rows of L are dealt round-robin to the waves; lanes stride R
+        for (uint32_t i = wave; i < nL; i += OVF_NW) {
+            const uint2 a = L[i];
+            for (uint32_t jb = 0; jb < nR; jb += 64) {
+                const uint32_t j = jb + lane;
+                const bool valid = j < nR;
+                uint2 b = make_uint2(0, 0);
+                if (valid) b = R[j];
+                const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
+                const bool pass = valid && (s > p.eps);                            // :91
+                if (pass && !(p.flags & 1u)) atomicMax(tab + (a.x * mulR + b.x), enc_score_bits(__float_as_uint(s)));
+                cnt += (uint32_t)__popcll(__ballot(pass));
+            }
+        }
+        emitted += cnt;
     }
-    if (lane_id() == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
+    if (lane == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
 }
-
 
 // =================================================================================================
 // Two-pass radix max-reduce ("stream" variant): scattered global atomics run at ~25-45 G/s on MI355X
