@@ -195,6 +195,30 @@ const void* ipkgpu_db_entries_device(const ipkgpu_db* d);
 double ipkgpu_db_time_ms(const ipkgpu_db* d);
 void ipkgpu_db_free(ipkgpu_db* d);
 
+/* ---- "next" row n1: MIF0 filter values and k-mer order (filter.cpp:55-119, db_builder.cpp:254-284) -- */
+
+/* IPK's score threshold itself (un-vendored i2l::score_threshold; assumed powf(omega/sigma, k)). */
+float ipkgpu_score_threshold(float omega, uint32_t sigma, uint32_t k);
+
+/*
+ * mif0_filter::calc_filter_values over a database shard, then the order of db_builder.cpp:284
+ * (ascending filter value; ties -- unspecified in the reference -- by ascending key).
+ *   total_num_groups  N = node count of the original tree (db_builder.cpp:261)
+ *   threshold         score_threshold(omega, k), NOT its log (db_builder.cpp:260)
+ * Filter values are per k-mer, so a shard is filtered independently of the other owners.
+ * Double arithmetic on the device: agrees with the reference formula to ~1e-13 relative (parallel
+ * summation order, device pow/log2), not bit for bit.
+ */
+int ipkgpu_db_filter_mif0(ipkgpu_ctx* ctx, ipkgpu_db* db, uint64_t total_num_groups, float threshold);
+/* host copies: filter value per k-mer (as the float i2l::kmer_fv stores, and in double), and the
+ * positions of the k-mers in filter order: keys[order[0]] is written first */
+const float* ipkgpu_db_filter_values(ipkgpu_db* d);
+const double* ipkgpu_db_filter_values_f64(ipkgpu_db* d);
+const uint32_t* ipkgpu_db_filter_order(ipkgpu_db* d);
+const float* ipkgpu_db_filter_values_device(const ipkgpu_db* d);
+const uint32_t* ipkgpu_db_filter_order_device(const ipkgpu_db* d);
+double ipkgpu_db_filter_time_ms(const ipkgpu_db* d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,9 @@
 //   result CSR: offsets[g], keys[] (bit-packed codes, ascending per group), scores[] f32
 //
 // There is NO CPU fallback: without a GPU ipkgpu_create fails with IPKGPU_ERR_NODEVICE.
+#include <cstring>
 #include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -29,6 +31,7 @@
 #include "kernels_score.hpp"
 #include "kernels_compact.hpp"
 #include "kernels_keymajor.hpp"
+#include "kernels_filter.hpp"
 
 using namespace ipkgpu;
 
@@ -105,6 +108,15 @@ struct ipkgpu_db {
     std::vector<uint32_t> h_entries;          // [n_entries][2]
     bool h_ok = false;
     double t_merge = 0;
+    // filter stage (row n1)
+    double* d_fv64 = nullptr;
+    float* d_fv32 = nullptr;
+    uint32_t* d_order = nullptr;              // positions of the k-mers sorted by (filter value, key)
+    std::vector<double> h_fv64;
+    std::vector<float> h_fv32;
+    std::vector<uint32_t> h_order;
+    bool h_filter_ok = false;
+    double t_filter = 0;
 };
 
 static std::string g_create_err;
@@ -1202,10 +1214,76 @@ const uint32_t* ipkgpu_db_keys(ipkgpu_db* d) { return d && db_to_host(d) ? d->h_
 const uint64_t* ipkgpu_db_key_offsets(ipkgpu_db* d) { return d && db_to_host(d) ? d->h_key_off.data() : nullptr; }
 const uint32_t* ipkgpu_db_entries(ipkgpu_db* d) { return d && db_to_host(d) ? d->h_entries.data() : nullptr; }
 
+float ipkgpu_score_threshold(float omega, uint32_t sigma, uint32_t k) { return powf(omega / (float)sigma, (float)k); }
+
+int ipkgpu_db_filter_mif0(ipkgpu_ctx* ctx, ipkgpu_db* db, uint64_t total_num_groups, float threshold)
+{
+    if (!ctx) return IPKGPU_ERR_INVALID;
+    if (!db || db->ctx != ctx) return fail(ctx, IPKGPU_ERR_INVALID, "database does not belong to this context");
+    if (total_num_groups == 0 || !(threshold > 0.0f)) return fail(ctx, IPKGPU_ERR_INVALID, "need total_num_groups > 0 and threshold > 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = db->n_keys;
+    ctx_release(ctx, db->d_fv64); ctx_release(ctx, db->d_fv32); ctx_release(ctx, db->d_order);
+    db->d_fv64 = nullptr; db->d_fv32 = nullptr; db->d_order = nullptr; db->h_filter_ok = false;
+    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_fv64, std::max<uint64_t>(n, 1) * 8));
+    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_fv32, std::max<uint64_t>(n, 1) * 4));
+    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_order, std::max<uint64_t>(n, 1) * 4));
+    if (n == 0) return IPKGPU_OK;
+    Stopwatch sw(ctx->stream);
+    const int t0 = sw.mark();
+    hipLaunchKernelGGL(mif0_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, ctx->stream, db->d_key_off, db->d_entries, n,
+                       (double)total_num_groups, (double)threshold, db->d_fv64, db->d_fv32);
+    HIP_TRY(ctx, hipGetLastError());
+    // order: ascending filter value (std::sort of kmer_order, db_builder.cpp:284), ties by ascending key
+    RC_TRY(ensure(ctx, ctx->tmp_a, n * 8));
+    RC_TRY(ensure(ctx, ctx->tmp_b, n * 8));
+    const uint32_t nb = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(filter_sortkey_kernel, dim3(nb), dim3(256), 0, ctx->stream, db->d_fv32, n, ctx->tmp_a.as<unsigned long long>());
+    HIP_TRY(ctx, hipGetLastError());
+    size_t tmp_bytes = 0;
+    HIP_TRY(ctx, rocprim::radix_sort_keys(nullptr, tmp_bytes, ctx->tmp_a.as<unsigned long long>(), ctx->tmp_b.as<unsigned long long>(),
+                                          (size_t)n, 0, 64, ctx->stream));
+    RC_TRY(ensure(ctx, ctx->tmp_c, tmp_bytes));
+    HIP_TRY(ctx, rocprim::radix_sort_keys(ctx->tmp_c.p, tmp_bytes, ctx->tmp_a.as<unsigned long long>(), ctx->tmp_b.as<unsigned long long>(),
+                                          (size_t)n, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(filter_order_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->tmp_b.as<unsigned long long>(), n, db->d_order);
+    HIP_TRY(ctx, hipGetLastError());
+    const int t1 = sw.mark();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    db->t_filter = sw.ms(t0, t1);
+    return IPKGPU_OK;
+}
+
+static bool db_filter_to_host(ipkgpu_db* d)
+{
+    if (d->h_filter_ok) return true;
+    if (!d->d_fv64) return false;
+    (void)hipSetDevice(d->ctx->device);
+    const uint64_t n = d->n_keys;
+    d->h_fv64.resize(std::max<uint64_t>(n, 1)); d->h_fv32.resize(std::max<uint64_t>(n, 1)); d->h_order.resize(std::max<uint64_t>(n, 1));
+    if (n) {
+        if (hipMemcpy(d->h_fv64.data(), d->d_fv64, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (hipMemcpy(d->h_fv32.data(), d->d_fv32, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (hipMemcpy(d->h_order.data(), d->d_order, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    }
+    d->h_filter_ok = true;
+    return true;
+}
+const double* ipkgpu_db_filter_values_f64(ipkgpu_db* d) { return d && db_filter_to_host(d) ? d->h_fv64.data() : nullptr; }
+const float* ipkgpu_db_filter_values(ipkgpu_db* d) { return d && db_filter_to_host(d) ? d->h_fv32.data() : nullptr; }
+const uint32_t* ipkgpu_db_filter_order(ipkgpu_db* d) { return d && db_filter_to_host(d) ? d->h_order.data() : nullptr; }
+const float* ipkgpu_db_filter_values_device(const ipkgpu_db* d) { return d ? d->d_fv32 : nullptr; }
+const uint32_t* ipkgpu_db_filter_order_device(const ipkgpu_db* d) { return d ? d->d_order : nullptr; }
+double ipkgpu_db_filter_time_ms(const ipkgpu_db* d) { return d ? d->t_filter : 0; }
+
 void ipkgpu_db_free(ipkgpu_db* d)
 {
     if (!d) return;
-    if (d->ctx) { (void)hipSetDevice(d->ctx->device); ctx_release(d->ctx, d->d_keys); ctx_release(d->ctx, d->d_key_off); ctx_release(d->ctx, d->d_entries); }
+    if (d->ctx) {
+        (void)hipSetDevice(d->ctx->device);
+        ctx_release(d->ctx, d->d_keys); ctx_release(d->ctx, d->d_key_off); ctx_release(d->ctx, d->d_entries);
+        ctx_release(d->ctx, d->d_fv64); ctx_release(d->ctx, d->d_fv32); ctx_release(d->ctx, d->d_order);
+    }
     delete d;
 }
 

@@ -103,6 +103,12 @@ def bits_per_symbol(sigma):
     return int(load_library().ipkgpu_bits_per_symbol(sigma))
 
 
+def score_threshold(omega, sigma, k):
+    L = load_library()
+    _bind_keymajor(L)
+    return float(L.ipkgpu_score_threshold(C.c_float(omega), sigma, k))
+
+
 def kmer_batch(key, n_ranges):
     return int(load_library().ipkgpu_kmer_batch(key, n_ranges))
 
@@ -276,6 +282,21 @@ def _bind_keymajor(L):
     L.ipkgpu_db_time_ms.argtypes = [C.c_void_p]
     L.ipkgpu_db_free.restype = None
     L.ipkgpu_db_free.argtypes = [C.c_void_p]
+    L.ipkgpu_score_threshold.restype = C.c_float
+    L.ipkgpu_score_threshold.argtypes = [C.c_float, C.c_uint32, C.c_uint32]
+    L.ipkgpu_db_filter_mif0.restype = C.c_int
+    L.ipkgpu_db_filter_mif0.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float]
+    L.ipkgpu_db_filter_values.restype = C.POINTER(C.c_float)
+    L.ipkgpu_db_filter_values.argtypes = [C.c_void_p]
+    L.ipkgpu_db_filter_values_f64.restype = C.POINTER(C.c_double)
+    L.ipkgpu_db_filter_values_f64.argtypes = [C.c_void_p]
+    L.ipkgpu_db_filter_order.restype = u32p
+    L.ipkgpu_db_filter_order.argtypes = [C.c_void_p]
+    for n in ("ipkgpu_db_filter_values_device", "ipkgpu_db_filter_order_device"):
+        getattr(L, n).restype = C.c_void_p
+        getattr(L, n).argtypes = [C.c_void_p]
+    L.ipkgpu_db_filter_time_ms.restype = C.c_double
+    L.ipkgpu_db_filter_time_ms.argtypes = [C.c_void_p]
     L._km_bound = True
 
 
@@ -286,6 +307,9 @@ ABI_SYMBOLS += [
     "ipkgpu_db_num_keys", "ipkgpu_db_num_entries", "ipkgpu_db_keys", "ipkgpu_db_key_offsets", "ipkgpu_db_entries",
     "ipkgpu_db_keys_device", "ipkgpu_db_key_offsets_device", "ipkgpu_db_entries_device", "ipkgpu_db_time_ms",
     "ipkgpu_db_free", "ipkgpu_db_from_parts",
+    "ipkgpu_score_threshold", "ipkgpu_db_filter_mif0", "ipkgpu_db_filter_values", "ipkgpu_db_filter_values_f64",
+    "ipkgpu_db_filter_order", "ipkgpu_db_filter_values_device", "ipkgpu_db_filter_order_device",
+    "ipkgpu_db_filter_time_ms",
 ]
 
 
@@ -357,6 +381,33 @@ class Db:
             return np.zeros(0, np.uint32), np.zeros(0, np.float32)
         e = np.ctypeslib.as_array(self._lib.ipkgpu_db_entries(self._h), shape=(self.num_entries, 2))
         return e[:, 0].copy(), e[:, 1].copy().view(np.float32)
+
+    def filter_mif0(self, engine, total_num_groups, threshold):
+        """MIF0 filter values + k-mer order (filter.cpp:55-119, db_builder.cpp:281-284) on the device."""
+        rc = self._lib.ipkgpu_db_filter_mif0(engine._h, self._h, int(total_num_groups), C.c_float(threshold))
+        if rc != 0:
+            raise engine._err(rc)
+
+    def filter_values(self, f64=False):
+        n = self.num_keys
+        if n == 0:
+            return np.zeros(0, np.float64 if f64 else np.float32)
+        p = (self._lib.ipkgpu_db_filter_values_f64 if f64 else self._lib.ipkgpu_db_filter_values)(self._h)
+        if not p:
+            raise IpkGpuError(1, "filter values not computed")
+        return np.ctypeslib.as_array(p, shape=(n,))
+
+    def filter_order(self):
+        n = self.num_keys
+        if n == 0:
+            return np.zeros(0, np.uint32)
+        p = self._lib.ipkgpu_db_filter_order(self._h)
+        if not p:
+            raise IpkGpuError(1, "filter order not computed")
+        return np.ctypeslib.as_array(p, shape=(n,))
+
+    def filter_time_ms(self):
+        return float(self._lib.ipkgpu_db_filter_time_ms(self._h))
 
     def keys_device_ptr(self):
         return self._lib.ipkgpu_db_keys_device(self._h)

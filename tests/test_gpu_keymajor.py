@@ -113,3 +113,34 @@ def test_full_size_keymajor_sampled(engine):
         assert np.array_equal(key_of_entry[sel], gk)
         assert np.array_equal(s[sel].view(np.uint32), gs.view(np.uint32))
     res.free(); db.free(); parts.free()
+
+
+@pytest.mark.parametrize("sigma,k,sites", [(4, 8, 80), (20, 3, 24)])
+def test_mif0_filter_values_and_order(engine, sigma, k, sites):
+    """Row n1: mif0_filter::calc_filter_values (filter.cpp:55-119) + the sort of db_builder.cpp:284."""
+    import ipk_amd
+    n_groups = 9
+    mats = synth_matrices(n_groups * 2, sites, sigma, 0.1, 321 + k)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 1, 2)
+    eps = co.log_threshold(1.5, sigma, k)
+    thr = ipk_amd.score_threshold(1.5, sigma, k)
+    assert abs(thr - co.score_threshold(1.5, sigma, k)) == 0.0
+    N = 2 * n_groups - 1                                  # node count of a rooted binary tree with n_groups+... (any N >= n)
+    db, parts = D.build_db_shard(engine, mats, groups, k, eps, sigma)
+    db.filter_mif0(engine, N, thr)
+    fv64, fv32, order = db.filter_values(f64=True), db.filter_values(), db.filter_order()
+    off = db.key_offsets()
+    _, sc = db.entries()
+    # values: double formula of the oracle (sequential sums), tolerance 1e-9 relative (device sums in parallel)
+    idx = np.linspace(0, db.num_keys - 1, 400).astype(np.int64)
+    for i in idx:
+        ref = co.mif0(sc[int(off[i]):int(off[i + 1])], N, thr)
+        assert abs(fv64[i] - ref) <= 1e-9 * max(1.0, abs(ref)), (i, fv64[i], ref)
+    assert np.array_equal(fv32, fv64.astype(np.float32))
+    # order: a permutation, ascending float filter value, ties by ascending position (= ascending key)
+    assert np.array_equal(np.sort(order), np.arange(db.num_keys, dtype=np.uint32))
+    f = fv32[order]
+    assert np.all(np.diff(f) >= 0)
+    ties = np.diff(f) == 0
+    assert np.all(np.diff(order.astype(np.int64))[ties] > 0)
+    db.free(); parts.free()
