@@ -219,6 +219,24 @@ const float* ipkgpu_db_filter_values_device(const ipkgpu_db* d);
 const uint32_t* ipkgpu_db_filter_order_device(const ipkgpu_db* d);
 double ipkgpu_db_filter_time_ms(const ipkgpu_db* d);
 
+/* ---- "next" row n3: RAxML-ng ancestral-probabilities loader (host, multi-threaded) -------------------- */
+
+typedef struct ipkgpu_ar ipkgpu_ar;
+
+/* raxmlng_reader (ar.cpp:144-188): memory-maps `<prefix>.raxml.ancestralProbs` (TSV, one header line, rows
+ * `Node \t Site \t State \t p_1 .. p_sigma`, contiguous per node) and indexes the node blocks. */
+int ipkgpu_ar_open(const char* path, uint32_t sigma, ipkgpu_ar** out);
+void ipkgpu_ar_close(ipkgpu_ar* ar);
+const char* ipkgpu_ar_last_error(void);           /* message of the last failing ipkgpu_ar_* call of this thread */
+uint32_t ipkgpu_ar_num_nodes(const ipkgpu_ar* ar);
+uint32_t ipkgpu_ar_sites(const ipkgpu_ar* ar);    /* rows of the first node's block */
+const char* ipkgpu_ar_node_label(const ipkgpu_ar* ar, uint32_t i);   /* labels in order of first appearance */
+int64_t ipkgpu_ar_find(const ipkgpu_ar* ar, const char* label);      /* -1 if absent */
+/* raxmlng_reader::read_node (ar.cpp:200-270) for n nodes at once: out[i] = [sites][sigma] float32 log10
+ * posteriors of node node_idx[i] (AA columns permuted to IPK order), ready for ipkgpu_score_groups.
+ * n_threads = 0 uses all host cores. */
+int ipkgpu_ar_read_nodes(ipkgpu_ar* ar, const uint32_t* node_idx, uint32_t n, float* out, uint32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libipkgpu.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-pthread"]
 
 
 def _stale(target, sources):
@@ -23,7 +23,7 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
     hdrs = [os.path.join(HERE, "..", "include", "ipkgpu.h")]
     if force or _stale(LIB, srcs + hdrs):
-        units = [s for s in srcs if s.endswith(".hip")]
+        units = [s for s in srcs if s.endswith((".hip", ".cpp"))]
         cmd = [HIPCC] + FLAGS + ["-o", LIB] + units
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -330,3 +330,9 @@ void ipko_window_halves(const float* m, const float* best, unsigned sigma, unsig
     *nl = l.n; *nr = r.n;
     free(l.v); free(r.v);
 }
+
+/* log10 in float exactly as the reference applies it (std::log10(float) -> log10f, ar.cpp:257-259). */
+void ipko_log10f(const float* in, size_t n, float* out)
+{
+    for (size_t i = 0; i < n; ++i) out[i] = log10f(in[i]);
+}

@@ -57,6 +57,8 @@ def lib():
         L.ipko_explore_many.restype = C.c_uint64
         L.ipko_explore_many.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint,
                                         C.c_float, C.POINTER(C.c_uint64)]
+        L.ipko_log10f.restype = None
+        L.ipko_log10f.argtypes = [f32p, C.c_size_t, f32p]
         _lib = L
     return _lib
 
@@ -145,3 +147,11 @@ def kmer_batch(key, n):
 def mif0(log_scores, N, threshold):
     a, ap = _f32(log_scores)
     return float(lib().ipko_mif0(ap, a.size, N, C.c_float(threshold)))
+
+
+def log10f(a):
+    """libm log10f element-wise (numpy's own float32 log10 can differ in the last bit)."""
+    a, ap = _f32(a)
+    out = np.empty_like(a)
+    lib().ipko_log10f(ap, a.size, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
