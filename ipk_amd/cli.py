@@ -1,0 +1,131 @@
+"""`ipk build`-compatible command line for the MI355X engine.
+
+Option names and defaults follow the reference wrapper (ipk.py:70-230 -> argv table ipk.py:292-329,
+ipk/src/command_line.cpp:83-147).  Only the stages this repository owns run here: reading the RAxML-ng
+ancestral probabilities from --ar-dir, scoring on the GPU, MIF0 filter, database file.  Alignment
+reduction, tree extension, ancestral reconstruction and ghost-node mapping are IPK's host stages and out
+of scope: their options are accepted for command-line compatibility and ignored,
+and the ghost-node -> branch mapping they would produce is read from --mapping.
+
+  python -m ipk_amd.cli build -r aln.fasta -t tree.nwk -w work --ar-dir work/AR --mapping work/ghosts.tsv -k 10
+
+--mapping: TSV `ar_node_label <TAB> branch_postorder_id`, one line per ghost node (X0/X1), in the order the
+extended tree lists them (= group order, db_builder.cpp:576-627).  --ghosts inner-only / outer-only keep
+labels ending in _X0 / _X1 only (db_builder.cpp:495-507) when the labels carry those suffixes.
+"""
+import glob
+import os
+import sys
+import time
+
+import click
+import numpy as np
+
+
+@click.group()
+def ipk():
+    """MI355X phylo-k-mer database builder (drop-in for the scoring path of IPK)."""
+
+
+@ipk.command()
+@click.option("-b", "--ar", type=click.Path(), help="(ignored) ancestral-reconstruction binary; use --ar-dir")
+@click.option("-r", "--refalign", type=click.Path(), help="(ignored here) reference alignment")
+@click.option("-t", "--reftree", type=click.Path(), help="reference tree (newick); stored in the database header")
+@click.option("-s", "--states", type=click.Choice(["nucl", "amino"]), default="nucl", show_default=True)
+@click.option("-v", "--verbosity", type=int, default=1, show_default=True)
+@click.option("-w", "--workdir", required=True, type=click.Path(file_okay=False))
+@click.option("--write-reduction", type=click.Path(), help="(ignored)")
+@click.option("-a", "--alpha", type=float, default=1.0, show_default=True, help="(ignored) AR gamma shape")
+@click.option("-c", "--categories", type=int, default=4, show_default=True, help="(ignored) AR rate categories")
+@click.option("-k", "--k", "k", type=int, default=8, show_default=True, help="k-mer length (DNA <= 12, AA <= 6 on this engine)")
+@click.option("-m", "--model", default=None, help="(ignored) AR model")
+@click.option("--convert-uo", is_flag=True, help="(ignored)")
+@click.option("--no-reduction", is_flag=True, help="(ignored)")
+@click.option("--reduction-ratio", type=float, default=0.99, show_default=True, help="(ignored)")
+@click.option("--omega", type=float, default=1.5, show_default=True, help="score threshold (omega/#states)^k")
+@click.option("--filter", "filter_", type=click.Choice(["mif0", "random"]), default="mif0", show_default=True)
+@click.option("-u", "--mu", type=float, default=1.0, show_default=True, help="(parsed, unused -- as in the reference build)")
+@click.option("--ghosts", type=click.Choice(["inner-only", "outer-only", "both"]), default="both", show_default=True)
+@click.option("--use-unrooted", is_flag=True, help="(ignored)")
+@click.option("--merge-branches", is_flag=True, help="unsupported (as in the reference, main.cpp:31-37)")
+@click.option("--ar-dir", type=click.Path(exists=True, file_okay=False), required=True,
+              help="directory holding <prefix>.raxml.ancestralProbs")
+@click.option("--ar-only", is_flag=True, help="(ignored)")
+@click.option("--ar-config", type=click.Path(), help="(ignored)")
+@click.option("--keep-positions", is_flag=True, help="unsupported on this engine")
+@click.option("--uncompressed", is_flag=True, help="(ignored, as in the reference)")
+@click.option("--threads", type=int, default=1, show_default=True, help="host threads of the probability loader")
+@click.option("-o", "--output", default=None, help="output file [workdir/DB.ipkgpu]")
+@click.option("--on-disk", is_flag=True, help="(ignored: the GPU build batches groups by HBM instead)")
+@click.option("--mapping", type=click.Path(exists=True), required=True,
+              help="TSV: AR node label <TAB> branch post-order id, one line per ghost node")
+@click.option("--num-tree-nodes", type=int, default=0, help="node count of the original tree (MIF0's N); default 2*branches+1")
+@click.option("--device", type=int, default=0, show_default=True, help="GPU index")
+def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, alpha, categories, k, model, convert_uo,
+          no_reduction, reduction_ratio, omega, filter_, mu, ghosts, use_unrooted, merge_branches, ar_dir, ar_only,
+          ar_config, keep_positions, uncompressed, threads, output, on_disk, mapping, num_tree_nodes, device):
+    """Computes a database of phylo-k-mers from precomputed ancestral probabilities."""
+    import ipk_amd
+    from ipk_amd import dbfile, distributed
+    from ipk_amd.loader import AncestralProbs
+
+    if merge_branches or keep_positions:
+        raise click.UsageError("--merge-branches / --keep-positions are not supported")
+    sigma = 4 if states == "nucl" else 20
+    if not 2 <= k <= ipk_amd.max_k(sigma):
+        raise click.UsageError(f"k must be in [2, {ipk_amd.max_k(sigma)}] for --states {states} on this engine")
+    os.makedirs(workdir, exist_ok=True)
+    output = output or os.path.join(workdir, "DB.ipkgpu")
+    probs = sorted(glob.glob(os.path.join(ar_dir, "*.raxml.ancestralProbs")))        # ar.cpp:611-640 suffix lookup
+    if not probs:
+        raise click.UsageError(f"no *.raxml.ancestralProbs in {ar_dir}")
+
+    labels, branches = [], []
+    for line in open(mapping):
+        line = line.rstrip("\n")
+        if not line or line.startswith("#"):
+            continue
+        lab, br = line.split("\t")[:2]
+        if ghosts == "inner-only" and not lab.endswith("_X0"):
+            continue
+        if ghosts == "outer-only" and not lab.endswith("_X1"):
+            continue
+        labels.append(lab); branches.append(int(br))
+    if not labels:
+        raise click.UsageError("the mapping selects no ghost nodes")
+
+    t0 = time.time()
+    arp = AncestralProbs(probs[0], sigma)
+    mats = arp.read(labels, n_threads=max(1, threads))
+    t_load = time.time() - t0
+    log_eps = ipk_amd.log_threshold(omega, sigma, k)
+    eng = ipk_amd.Engine(device)
+    t0 = time.time()
+    db, parts = distributed.build_db_shard(eng, mats, np.array(branches, dtype=np.uint32), k, log_eps, sigma)
+    t_score = time.time() - t0
+    n_nodes = num_tree_nodes or 2 * len(set(branches)) + 1
+    t0 = time.time()
+    if filter_ == "mif0":
+        db.filter_mif0(eng, n_nodes, ipk_amd.score_threshold(omega, sigma, k))
+        fv, order = db.filter_values().copy(), db.filter_order().copy()
+    else:                                                   # random_filter: filter.cpp:133-146 (engine 42)
+        fv = np.random.default_rng(42).random(db.num_keys).astype(np.float32)
+        order = np.lexsort((db.keys(), fv))
+    t_filter = time.time() - t0
+    newick = open(reftree).read().strip() if reftree and os.path.exists(reftree) else ""
+    br, sc = db.entries()
+    t0 = time.time()
+    dbfile.write_db(output, "DNA" if sigma == 4 else "AA", [], newick, k, omega, db.keys(), db.key_offsets(), br, sc, fv, order)
+    t_write = time.time() - t0
+    if verbosity:
+        # the reference prints the same three stage timers (db_builder.cpp:236,290,336)
+        click.echo(f"Loaded {len(labels)} node matrices ({arp.sites} sites) in {t_load * 1e3:.0f} ms")
+        click.echo(f"Computation time: {t_score * 1e3:.0f} ms ({parts.emitted} scored phylo-k-mers)")
+        click.echo(f"Filtering time: {t_filter * 1e3:.0f} ms")
+        click.echo(f"Merge time: {t_write * 1e3:.0f} ms")
+        click.echo(f"Output: {output} ({db.num_keys} k-mers, {db.num_entries} entries)")
+    db.free(); parts.free(); eng.close(); arp.close()
+
+
+if __name__ == "__main__":
+    ipk()
