@@ -48,9 +48,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # rehearsal aids for a one-GPU box (never set by the driver): IPK_BENCH_DEVICE pins every rank to one GPU,
+    # IPK_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if os.environ.get("IPK_BENCH_DEVICE"):
+        local_rank = int(os.environ["IPK_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("IPK_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = dict(CONFIGS[args.config])
     if args.groups:
@@ -140,7 +148,8 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("workload") == args.config and tj.get("kernel", "").startswith(main_kernel.split("_kernel")[0]):
+                if (tj.get("workload") == args.config and not args.groups and not args.alpha
+                        and tj.get("kernel", "").startswith(main_kernel.split("_kernel")[0])):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

@@ -33,6 +33,10 @@ def exchange_parts(counts, entries, owner_offsets, dist, world):
     send_sizes = [int(owner_offsets[o + 1] - owner_offsets[o]) for o in range(world)]
     if world == 1:
         return counts, entries, np.zeros(1, dtype=np.uint64)
+    if dev.type == "cuda" and dist.get_backend() == "gloo":
+        # rehearsal / test transport: gloo has no device all-to-all, stage through host memory
+        rc, re_, so = exchange_parts(counts.cpu(), entries.cpu(), owner_offsets, dist, world)
+        return rc.to(dev), re_.to(dev), so
     ss = torch.tensor(send_sizes, dtype=torch.int64, device=dev)
     rs = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(rs, ss)

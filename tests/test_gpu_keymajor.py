@@ -144,3 +144,49 @@ def test_mif0_filter_values_and_order(engine, sigma, k, sites):
     ties = np.diff(f) == 0
     assert np.all(np.diff(order.astype(np.int64))[ties] > 0)
     db.free(); parts.free()
+
+
+def _rank_worker(rank, world, port, out_dir):
+    """One process per rank (both on GPU 0, gloo transport): the bench's N>1 path end to end."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import ipk_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        sigma, k, n_groups, mpg, sites = 4, 8, 6, 2, 120
+        mats = synth_matrices(n_groups * mpg, sites, sigma, 0.1, 4242)
+        groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 50, mpg)
+        g0, g1 = D.shard_range(n_groups, world, rank)
+        eng = ipk_amd.Engine(0)
+        db, parts = D.build_db_shard(eng, torch.from_numpy(mats[g0 * mpg:g1 * mpg]).cuda(), groups[g0 * mpg:g1 * mpg], k,
+                                     co.log_threshold(1.5, sigma, k), sigma, dist, world, rank)
+        b, s = db.entries()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=db.keys(), off=db.key_offsets(), br=b, sc=s.view(np.uint32),
+                 emitted=parts.emitted)
+        db.free(); parts.free(); eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_build_with_exchange(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    world = 2
+    mp.spawn(_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sigma, k, n_groups, mpg, sites = 4, 8, 6, 2, 120
+    mats = synth_matrices(n_groups * mpg, sites, sigma, 0.1, 4242)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 50, mpg)
+    full, emitted = oracle_db(mats, groups, k, co.log_threshold(1.5, sigma, k))
+    tot = 0
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        keys, off, br, sc = dbo.db_shard_arrays(full, sigma, k, r, world)
+        assert np.array_equal(z["keys"], keys) and np.array_equal(z["off"], off)
+        assert np.array_equal(z["br"], br) and np.array_equal(z["sc"], sc)
+        tot += int(z["emitted"])
+    assert tot == emitted

@@ -146,3 +146,18 @@ def test_full_size_matrices_sampled(engine):
 def test_full_size_aa_sampled(engine):
     mats = synth_matrices(2, 3000, 20, 0.03, 43)
     check_against_oracle(engine, mats, [0, 0], 6, co.log_threshold(1.5, 20, 6), device=True)
+
+
+def test_empty_results(engine):
+    """A threshold nothing can pass: every group is empty, offsets stay flat, nothing is emitted."""
+    mats = synth_matrices(4, 30, 4, 0.3, 77)
+    res = engine.score_groups(mats, [3, 3, 8, 8], 8, 0.5)          # log scores are <= 0 < 0.5
+    assert res.emitted == 0 and res.num_entries == 0 and res.offsets.tolist() == [0, 0, 0]
+    assert res.group_ids.tolist() == [3, 8]
+    res.free()
+    from ipk_amd import distributed as D
+    db, parts = D.build_db_shard(engine, mats, np.array([3, 3, 8, 8], dtype=np.uint32), 8, 0.5, 4)
+    assert db.num_keys == 0 and db.num_entries == 0 and parts.emitted == 0
+    db.filter_mif0(engine, 5, 0.001)
+    assert len(db.filter_order()) == 0
+    db.free(); parts.free()
