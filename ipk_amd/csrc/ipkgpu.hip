@@ -57,6 +57,7 @@ struct ipkgpu_ctx {
     int64_t opt_list_cap = 0;
     int64_t opt_variant = 0;
     int64_t opt_flags = 0;
+    int64_t opt_pool_chunks = 0;      // test knob: size of the FIRST pair-pool attempt (forces the grow-and-redo path)
     DevBuf table, best, ovfq, counts, offsets, goff, idx, branch, scan_sums, scan_boff, tmp_a, tmp_b, tmp_c;
     DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
@@ -286,6 +287,7 @@ int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "list_cap")) { ctx->opt_list_cap = value; return IPKGPU_OK; }
     if (!strcmp(name, "variant")) { ctx->opt_variant = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_flags")) { ctx->opt_flags = value; return IPKGPU_OK; }
+    if (!strcmp(name, "debug_pool_chunks")) { ctx->opt_pool_chunks = value; return IPKGPU_OK; }
     return fail(ctx, IPKGPU_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -619,10 +621,12 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     uint64_t want = (uint64_t)((double)windows * ppw / CH) + 2 * n_waves * NBK * SUB + n_waves * ALLOC_BATCH + 1024;
     for (int attempt = 0; attempt < 6; ++attempt) {
         uint64_t cap = std::min<uint64_t>(want, max_chunks);
-        if (cap < n_waves * NBK * SUB) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool does not fit device memory (lower workspace_bytes)");
+        const bool forced = attempt == 0 && ctx->opt_pool_chunks > 0;
+        if (forced) cap = (uint64_t)ctx->opt_pool_chunks;
+        else if (cap < n_waves * NBK * SUB) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool does not fit device memory (lower workspace_bytes)");
         RC_TRY(ensure(ctx, ctx->pool, cap * CH * 8));
         RC_TRY(ensure(ctx, ctx->desc, cap * 8));
-        cap = std::min<uint64_t>(ctx->pool.cap / (CH * 8), ctx->desc.cap / 8);
+        if (!forced) cap = std::min<uint64_t>(ctx->pool.cap / (CH * 8), ctx->desc.cap / 8);
         RC_TRY(ensure(ctx, ctx->gbcnt, n_gb * 4));
         RC_TRY(ensure(ctx, ctx->gbcur, n_gb * 4));
         RC_TRY(ensure(ctx, ctx->gboff, (n_gb + 1) * 8));

@@ -161,3 +161,33 @@ def test_empty_results(engine):
     db.filter_mif0(engine, 5, 0.001)
     assert len(db.filter_order()) == 0
     db.free(); parts.free()
+
+
+def test_pair_pool_exhaustion_is_redone(engine):
+    """The pair pool of the stream variant is sized from an estimate; when it runs out the batch is redone
+    with a bigger pool.  Force that path with a tiny first pool: results must not change."""
+    mats = synth_matrices(4, 600, 4, 1.0, 123)          # flat columns: ~600 pairs per window
+    eps = co.log_threshold(1.5, 4, 10)
+    engine.set_option("debug_pool_chunks", 40)
+    try:
+        check_against_oracle(engine, mats, [1, 1, 2, 2], 10, eps)
+        check_against_oracle(engine, mats, [1, 1, 2, 2], 10, eps, device=True)
+    finally:
+        engine.set_option("debug_pool_chunks", 0)
+    check_against_oracle(engine, mats, [1, 1, 2, 2], 10, eps)
+
+
+def test_many_small_groups_and_single_matrix_groups(engine):
+    # 300 groups of one short matrix each: many (group, segment) workgroups with almost no work
+    mats = synth_matrices(300, 24, 4, 0.2, 555)
+    check_against_oracle(engine, mats, np.arange(300, dtype=np.uint32) * 7 + 1, 8, co.log_threshold(1.5, 4, 8))
+
+
+def test_v1_variant_still_matches(engine):
+    """variant=1 (global-atomic max-reduce, the round's first kernel) stays available and bit-exact."""
+    mats = synth_matrices(4, 300, 4, 0.1, 99)
+    engine.set_option("variant", 1)
+    try:
+        check_against_oracle(engine, mats, [0, 0, 1, 1], 10, co.log_threshold(1.5, 4, 10))
+    finally:
+        engine.set_option("variant", 0)
