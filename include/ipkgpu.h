@@ -64,8 +64,9 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx);
 const char* ipkgpu_last_error(const ipkgpu_ctx* ctx);
 
 /* Options: "workspace_bytes" (max bytes of per-group score tables resident at once; groups are
- * processed in batches that fit), "list_cap" (half-list capacity of the fast path; 0 = auto),
- * "variant" (scoring kernel variant, 0 = auto).  Returns IPKGPU_ERR_INVALID for unknown names. */
+ * processed in batches that fit); "variant" (0 = auto: two-pass LDS max-reduce where available,
+ * 1 = global-atomic max-reduce, 2 = force the two-pass form); "debug_flags" / "debug_pool_chunks"
+ * (diagnostics and tests only).  Returns IPKGPU_ERR_INVALID for unknown names. */
 int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value);
 
 /* ---- host helpers (no GPU needed) ------------------------------------------------------ */

@@ -18,6 +18,8 @@
 // One wavefront owns one window at a time: a node's sigma^h candidates (h small) are evaluated
 // one per lane; larger nodes are the filtered cross product of their children's lists, lanes
 // striding the flattened candidate space, survivors compacted with ballot + mbcnt into LDS.
+// Lists come out in ascending code order (lane order, then (left, right) order of the joins) --
+// the pair appender of the stream variant relies on that for its bucket runs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -7,9 +7,12 @@
 // Data layout in HBM:
 //   logp   [n_mats][sites][sigma] f32        caller's matrices, read once per scoring pass
 //   best   [n_mats][sites+1]      f32        sequential float prefix sums of column maxima
+//   pool   [chunks][256] {u32 code, f32 score}   every scored phylo-k-mer once (stream variant), chunked
+//                                            per (wavefront, key bucket); desc[chunk] = (group, bucket, count)
 //   table  [groups_in_batch][sigma^k] u32    per-group dense max table, order-preserving score
 //                                            codes, 0 = empty (the on-device group_hash_map)
-//   result CSR: offsets[g], keys[] (bit-packed codes, ascending per group), scores[] f32
+//   results: group-major CSR (offsets, keys, scores) or key-major parts / database shards
+//            (counts per key, {branch, score} entries) -- see include/ipkgpu.h
 //
 // There is NO CPU fallback: without a GPU ipkgpu_create fails with IPKGPU_ERR_NODEVICE.
 #include <cstring>
@@ -54,7 +57,6 @@ struct ipkgpu_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int64_t workspace_bytes = 0;
-    int64_t opt_list_cap = 0;
     int64_t opt_variant = 0;
     int64_t opt_flags = 0;
     int64_t opt_pool_chunks = 0;      // test knob: size of the FIRST pair-pool attempt (forces the grow-and-redo path)
@@ -284,7 +286,6 @@ int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value)
         ctx->workspace_bytes = value;
         return IPKGPU_OK;
     }
-    if (!strcmp(name, "list_cap")) { ctx->opt_list_cap = value; return IPKGPU_OK; }
     if (!strcmp(name, "variant")) { ctx->opt_variant = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_flags")) { ctx->opt_flags = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_pool_chunks")) { ctx->opt_pool_chunks = value; return IPKGPU_OK; }
@@ -296,12 +297,12 @@ int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value)
 // ---- launch plumbing --------------------------------------------------------------------------
 namespace {
 
-constexpr int TW = 64;   // windows per tile
-constexpr int NW = 4;    // wavefronts per workgroup
+constexpr int TW = 128;  // windows per tile
+constexpr int NW = 8;    // wavefronts per workgroup
 
 template <int SIGMA, int K> constexpr int fast_cap()
 {
-    if (SIGMA == 4) return K <= 10 ? 192 : 512;
+    if (SIGMA == 4) return K <= 10 ? 160 : 512;
     return 512;
 }
 
@@ -360,11 +361,6 @@ template <int SIGMA, int K> constexpr uint32_t stream_tbl()
     return 0;                                                           // AA k=6: 2000 buckets per group -> atomics variant
 }
 
-struct StreamLaunch {
-    uint32_t g0, gb;               // groups of the batch
-    uint32_t n_waves_total;
-    uint32_t S;
-};
 
 template <int SIGMA, int K>
 int launch_stream_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
@@ -405,6 +401,15 @@ int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* ta
     }
 }
 
+template <int SIGMA, int K> size_t stream_lds() {
+    constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
+    if constexpr (TBL == 0) return 0;
+    else {
+        constexpr int CAP = fast_cap<SIGMA, K>();
+        constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+        return TileGeo<SIGMA, K, TW>::HEAD_BYTES + (size_t)NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NW * 2 * NB * SUB * 4;
+    }
+}
 template <int SIGMA, int K> uint32_t stream_nb() {
     constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
     if constexpr (TBL == 0) return 0; else return (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
@@ -432,6 +437,13 @@ uint32_t stream_buckets(uint32_t sigma, uint32_t k)
 #define M_NB(S_, K_) return stream_nb<S_, K_>()
     IPK_DISPATCH(sigma, k, M_NB);
 #undef M_NB
+    return 0;
+}
+size_t stream_lds_bytes(uint32_t sigma, uint32_t k)
+{
+#define M_LDS(S_, K_) return stream_lds<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_LDS);
+#undef M_LDS
     return 0;
 }
 int dispatch_stream_pass1(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const StreamParams& sp, uint32_t n_wg)
@@ -605,13 +617,21 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     HIP_TRY(ctx, hipMemcpyAsync(ctx->gm.p, gm.data(), gm.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
-    // segments per group: enough workgroups to fill the chip, few enough that a wave's open chunks stay a small overhead
-    const uint32_t tiles_per_group_min = pl.tiles_per_mat;
-    uint32_t S = (uint32_t)std::max<uint64_t>(1, ((uint64_t)ctx->num_cu * 8 + gb - 1) / gb);
-    S = std::min<uint32_t>(S, std::max<uint32_t>(1, tiles_per_group_min));
+    // Segments (workgroups) per group.  More workgroups balance the tail of the persistent kernel, but every
+    // wavefront keeps one open chunk per key bucket, so workgroups x waves x buckets must stay well below
+    // the number of chunks the data itself fills (k = 12 has 512 buckets).
+    const uint64_t windows = (uint64_t)nb * pl.nwin;
+    const double ppw_est = ctx->pairs_per_window > 0 ? ctx->pairs_per_window : 256.0;
+    const size_t lds_bytes = stream_lds_bytes(pl.sigma, pl.k);
+    const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / NW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+    const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
+    const uint64_t expected_chunks = (uint64_t)((double)windows * ppw_est / CH);
+    const uint64_t max_wg = std::max<uint64_t>(slots, expected_chunks / 2 / ((uint64_t)NW * NBK * SUB));
+    uint64_t S64 = (slots * 8 + gb - 1) / gb;
+    S64 = std::min<uint64_t>(S64, std::max<uint64_t>(1, max_wg / gb));
+    uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(S64, pl.tiles_per_mat));
     const uint32_t n_wg = gb * S;
     const uint64_t n_waves = (uint64_t)n_wg * NW;
-    const uint64_t windows = (uint64_t)nb * pl.nwin;
     const uint64_t n_gb = (uint64_t)gb * NBK;
 
     size_t free_b = 0, total_b = 0;

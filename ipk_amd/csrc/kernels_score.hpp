@@ -417,7 +417,7 @@ struct Appender {
 };
 
 template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(96))) void score_stream_kernel(StreamParams p)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void score_stream_kernel(StreamParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     using TG = TileGeo<SIGMA, K, TW>;
