@@ -627,8 +627,9 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
     const uint64_t expected_chunks = (uint64_t)((double)windows * ppw_est / CH);
     const uint64_t max_wg = std::max<uint64_t>(slots, expected_chunks / 2 / ((uint64_t)NW * NBK * SUB));
-    uint64_t S64 = (slots * 8 + gb - 1) / gb;
-    S64 = std::min<uint64_t>(S64, std::max<uint64_t>(1, max_wg / gb));
+    // whole rounds of resident workgroups: a partial last round leaves CUs idle for a full workgroup's run time
+    const uint64_t rounds = std::max<uint64_t>(1, std::min<uint64_t>(8, max_wg / slots));
+    uint64_t S64 = std::max<uint64_t>(1, (slots * rounds) / gb);
     uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(S64, pl.tiles_per_mat));
     const uint32_t n_wg = gb * S;
     const uint64_t n_waves = (uint64_t)n_wg * NW;
@@ -637,8 +638,16 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const uint64_t max_chunks = std::min<uint64_t>(0xFFFFFFF0ull, (uint64_t)(free_b + ctx->pool.cap + ctx->desc.cap) * 9 / 10 / (CH * 8 + 8));
-    double ppw = ctx->pairs_per_window > 0 ? ctx->pairs_per_window * 1.25 : 256.0;
-    uint64_t want = (uint64_t)((double)windows * ppw / CH) + 2 * n_waves * NBK * SUB + n_waves * ALLOC_BATCH + 1024;
+    // pool size: pairs expected (calibrated by the previous call, +25 %) plus every wave's open chunks and id batches.
+    // An existing pool is kept as long as it covers the expectation without the margin -- regrowing a multi-GB
+    // buffer costs hundreds of ms, and an underestimate is caught by the redo path anyway.
+    const double ppw = ctx->pairs_per_window > 0 ? ctx->pairs_per_window : 256.0;
+    const uint64_t slack = 2 * n_waves * NBK * SUB + n_waves * ALLOC_BATCH + 1024;
+    uint64_t want = (uint64_t)((double)windows * ppw * 1.25 / CH) + slack;
+    {
+        const uint64_t have = std::min<uint64_t>(ctx->pool.cap / (CH * 8), ctx->desc.cap / 8);
+        if (have >= (uint64_t)((double)windows * ppw / CH) + slack) want = std::min<uint64_t>(want, have);
+    }
     for (int attempt = 0; attempt < 6; ++attempt) {
         uint64_t cap = std::min<uint64_t>(want, max_chunks);
         const bool forced = attempt == 0 && ctx->opt_pool_chunks > 0;
@@ -702,7 +711,6 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         const int ev_d = sw.mark();
         // windows whose half lists overflowed the fast path: big-list kernel, max-reduced into the finished tables
         RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
-        if (windows) ctx->pairs_per_window = (double)n_used * CH / (double)windows;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->acc_main_ms += sw.ms(ev_a, ev_b);
         ctx->acc_reduce_ms += sw.ms(ev_c, ev_d);
@@ -720,6 +728,11 @@ int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t
     HIP_TRY(ctx, hipMemcpyAsync(&e, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *emitted_acc += e;
+    // calibration of the next call's pair pool and workgroup count: PAIRS per window (not chunks -- chunk
+    // counts include every wave's open chunks and would feed back into the workgroup count)
+    uint64_t nb = 0;
+    for (uint32_t i = 0; i < pl.n_mats; ++i) nb += (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb);
+    if (nb) ctx->pairs_per_window = (double)e / ((double)nb * pl.nwin);
     return IPKGPU_OK;
 }
 
