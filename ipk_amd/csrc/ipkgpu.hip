@@ -358,9 +358,14 @@ template <int SIGMA, int K> constexpr uint32_t stream_tbl()
     if (SIGMA == 4) return T <= 16384 ? (uint32_t)T : (K <= 10 ? 16384u : 32768u);
     if (K <= 3) return (uint32_t)T;                                     // 400, 8000
     if (K <= 5) return 32000u;                                          // 20^4 = 5 x 32000, 20^5 = 100 x 32000
-    return 0;                                                           // AA k=6: 2000 buckets per group -> atomics variant
+    return 0;   // AA k=6: 2000 buckets per group.  Tried with two waves per workgroup (16 KB of chunk state per wave):
+                // pass 1 143 ms + reduce 19 ms vs 132 ms for the global-atomic variant -- occupancy-starved, so atomics stay
 }
 
+
+// AA k=6 keeps 2000 open chunks per wave (16 KB of LDS state): two waves per workgroup, 64-window tiles
+template <int SIGMA, int K> constexpr int stream_nw() { return (SIGMA == 20 && K == 6) ? 2 : NW; }
+template <int SIGMA, int K> constexpr int stream_tw() { return (SIGMA == 20 && K == 6) ? 64 : TW; }
 
 template <int SIGMA, int K>
 int launch_stream_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
@@ -371,12 +376,13 @@ int launch_stream_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
         constexpr int CAP = fast_cap<SIGMA, K>();
         constexpr uint32_t T = ipow(SIGMA, K);
         constexpr uint32_t NB = (T + TBL - 1) / TBL;
-        constexpr size_t lds = TileGeo<SIGMA, K, TW>::HEAD_BYTES + (size_t)NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NW * 2 * NB * SUB * 4;
+        constexpr int SNW = stream_nw<SIGMA, K>(), STW = stream_tw<SIGMA, K>();
+        constexpr size_t lds = TileGeo<SIGMA, K, STW>::HEAD_BYTES + (size_t)SNW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)SNW * 2 * NB * SUB * 4;
         static_assert(lds <= 160 * 1024, "stream pass-1 LDS budget");
-        auto kern = score_stream_kernel<SIGMA, K, CAP, TW, NW, TBL>;
+        auto kern = score_stream_kernel<SIGMA, K, CAP, STW, SNW, TBL>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NW * 64), lds, ctx->stream, sp);
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(SNW * 64), lds, ctx->stream, sp);
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
     }
@@ -407,7 +413,8 @@ template <int SIGMA, int K> size_t stream_lds() {
     else {
         constexpr int CAP = fast_cap<SIGMA, K>();
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
-        return TileGeo<SIGMA, K, TW>::HEAD_BYTES + (size_t)NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NW * 2 * NB * SUB * 4;
+        return TileGeo<SIGMA, K, stream_tw<SIGMA, K>()>::HEAD_BYTES + (size_t)stream_nw<SIGMA, K>() * stream_wave_scratch<SIGMA, K, CAP>() * 8 +
+               (size_t)stream_nw<SIGMA, K>() * 2 * NB * SUB * 4;
     }
 }
 template <int SIGMA, int K> uint32_t stream_nb() {
@@ -438,6 +445,20 @@ uint32_t stream_buckets(uint32_t sigma, uint32_t k)
     IPK_DISPATCH(sigma, k, M_NB);
 #undef M_NB
     return 0;
+}
+uint32_t stream_waves(uint32_t sigma, uint32_t k)
+{
+#define M_NWV(S_, K_) return (uint32_t)stream_nw<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_NWV);
+#undef M_NWV
+    return NW;
+}
+uint32_t stream_tile(uint32_t sigma, uint32_t k)
+{
+#define M_TWV(S_, K_) return (uint32_t)stream_tw<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_TWV);
+#undef M_TWV
+    return TW;
 }
 size_t stream_lds_bytes(uint32_t sigma, uint32_t k)
 {
@@ -590,7 +611,9 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     p.flags = (uint32_t)(ctx->opt_variant == 99 ? 1 : 0);
     HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
     const uint32_t NBK = stream_buckets(pl.sigma, pl.k);
-    const bool use_stream = NBK != 0 && NBK <= 1024 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
+    const bool use_stream = NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
+    const uint32_t SNW = stream_waves(pl.sigma, pl.k), STW = stream_tile(pl.sigma, pl.k);
+    const uint32_t s_tiles_per_mat = (pl.nwin + STW - 1) / STW;
     if (!use_stream) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->table.p, 0, (size_t)gb * pl.table_size * 4, ctx->stream));
         Stopwatch sw(ctx->stream);
@@ -623,16 +646,16 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const uint64_t windows = (uint64_t)nb * pl.nwin;
     const double ppw_est = ctx->pairs_per_window > 0 ? ctx->pairs_per_window : 256.0;
     const size_t lds_bytes = stream_lds_bytes(pl.sigma, pl.k);
-    const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / NW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+    const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / SNW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
     const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
     const uint64_t expected_chunks = (uint64_t)((double)windows * ppw_est / CH);
-    const uint64_t max_wg = std::max<uint64_t>(slots, expected_chunks / 2 / ((uint64_t)NW * NBK * SUB));
+    const uint64_t max_wg = std::max<uint64_t>(slots, expected_chunks / 2 / ((uint64_t)SNW * NBK * SUB));
     // whole rounds of resident workgroups: a partial last round leaves CUs idle for a full workgroup's run time
     const uint64_t rounds = std::max<uint64_t>(1, std::min<uint64_t>(8, max_wg / slots));
     uint64_t S64 = std::max<uint64_t>(1, (slots * rounds) / gb);
-    uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(S64, pl.tiles_per_mat));
+    uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(S64, s_tiles_per_mat));
     const uint32_t n_wg = gb * S;
-    const uint64_t n_waves = (uint64_t)n_wg * NW;
+    const uint64_t n_waves = (uint64_t)n_wg * SNW;
     const uint64_t n_gb = (uint64_t)gb * NBK;
 
     size_t free_b = 0, total_b = 0;
@@ -669,7 +692,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         StreamParams sp;
         sp.logp = logp_dev; sp.best = ctx->best.as<float>();
         sp.gm_off = ctx->gm.as<uint32_t>(); sp.gm_list = ctx->gm.as<uint32_t>() + gb + 1;
-        sp.sites = pl.sites; sp.nwin = pl.nwin; sp.tiles_per_mat = pl.tiles_per_mat; sp.S = S;
+        sp.sites = pl.sites; sp.nwin = pl.nwin; sp.tiles_per_mat = s_tiles_per_mat; sp.S = S;
         sp.eps = pl.eps;
         sp.pool = ctx->pool.as<uint2>(); sp.pool_cap = (uint32_t)cap; sp.pool_next = d_pool_next;
         sp.desc = ctx->desc.as<unsigned long long>(); sp.pool_ovf = d_pool_ovf;
