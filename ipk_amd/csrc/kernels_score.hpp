@@ -75,7 +75,7 @@ struct ScoreParams {
 // (nothing has been emitted for the window in that case).
 template <int SIGMA, int K, int CAP>
 __device__ __forceinline__ bool score_window(const WinCtx& c, float eps, uint2* scratch,
-                                             uint32_t* __restrict__ tab, uint32_t& emitted, bool no_put = false)
+                                             uint32_t* __restrict__ tab, unsigned long long& emitted, bool no_put = false)
 {
     if constexpr (Geo<SIGMA, K, CAP>::DIRECT) {
         const uint32_t lane = lane_id();
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
     const uint32_t wave = threadIdx.x >> 6;
     uint2* scratch = scratch_all + (size_t)wave * WS;
     uint32_t* tab = p.table + (size_t)p.mat_slot[mat] * p.table_size;
-    uint32_t emitted = 0;
+    unsigned long long emitted = 0;                     // per-wave count of scored phylo-k-mers (can pass 2^32 on flat data)
     for (uint32_t w = wave; w < nw; w += NW) {
         WinCtx c{cols, best, w};
         if (!score_window<SIGMA, K, CAP>(c, p.eps, scratch, tab, emitted, (p.flags & 1u) != 0)) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
             }
         }
     }
-    if (lane_id() == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
+    if (lane_id() == 0 && emitted) atomicAdd(p.emitted, emitted);
 }
 
 // Big-list path: windows whose half lists exceed the fast path's capacity.  One workgroup of OVF_NW
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
     uint2* scratch = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
     const uint32_t n = *p.ovf_count;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint32_t emitted = 0;
+    unsigned long long emitted = 0;                     // per-wave count of scored phylo-k-mers (can pass 2^32 on flat data)
     constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
     for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
         const unsigned long long e = p.ovf_queue[q];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
         }
         emitted += cnt;
     }
-    if (lane == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
+    if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);
 }
 
 // =================================================================================================
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void 
     uint32_t* cfill = cbase + NB * SUB;
     for (uint32_t b = lane; b < NB * SUB; b += 64) { cbase[b] = CHUNK_NONE; cfill[b] = CH; }
     Appender<TBL, NB> app{p, cbase, cfill, g};
-    uint32_t emitted = 0;
+    unsigned long long emitted = 0;                     // per-wave count of scored phylo-k-mers (can pass 2^32 on flat data)
     constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
 
     for (uint32_t t = t_lo; t < t_hi; ++t) {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void 
         const uint32_t id = cbase[b];
         if (id != CHUNK_NONE) p.desc[id] = ((unsigned long long)(g * NB + b / SUB) << 32) | (unsigned long long)min(cfill[b], CH);
     }
-    if (lane == 0 && emitted) atomicAdd(p.emitted, (unsigned long long)emitted);
+    if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);
 }
 
 // chunk index: how many chunks each (group, bucket) has; then chunk ids grouped by (group, bucket)

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the suites load the in-tree C-ABI library; build it (hipcc cross-compiles gfx950 without a GPU) if a fresh
+    # checkout has not run __graft_entry__.build() yet
+    from ipk_amd import build as hip_build
+    hip_build.build()
 
 
 @pytest.fixture(scope="session")
