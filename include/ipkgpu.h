@@ -120,6 +120,16 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
                                uint32_t sites, uint32_t sigma, const uint32_t* mat_group,
                                uint32_t k, float log_eps, ipkgpu_result** out);
 
+/* KEEP_POSITIONS flavour (`ipk-aa-pos`: db_builder.cpp:655-662,687-689; branch_group.cpp:73-86): every kept score
+ * carries the position (window start, window::get_position) of the window that produced it; on equal scores the
+ * window processed first (group's matrices in input order, then ascending start) keeps its place, as `put`
+ * replaces only on a strictly larger score.  Group-major output only; uses the global-atomic max-reduce with
+ * 64-bit table entries.  ipkgpu_result_positions() gives the positions aligned with keys/scores. */
+int ipkgpu_score_groups_positions(ipkgpu_ctx* ctx, const float* logp, uint32_t n_mats, uint32_t sites,
+                                  uint32_t sigma, const uint32_t* mat_group, uint32_t k, float log_eps,
+                                  ipkgpu_result** out);
+const uint32_t* ipkgpu_result_positions(ipkgpu_result* r);   /* NULL unless produced by the call above */
+
 /* ---- result accessors -------------------------------------------------------------------- */
 
 uint32_t ipkgpu_result_num_groups(const ipkgpu_result* r);

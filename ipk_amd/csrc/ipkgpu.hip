@@ -80,10 +80,12 @@ struct ipkgpu_result {
     uint64_t emitted = 0;
     uint32_t* d_keys = nullptr;
     float* d_scores = nullptr;
+    uint32_t* d_positions = nullptr;          // KEEP_POSITIONS variant only
     size_t cap = 0;
     std::vector<uint32_t> h_keys;
     std::vector<float> h_scores;
-    bool h_keys_ok = false, h_scores_ok = false;
+    std::vector<uint32_t> h_positions;
+    bool h_keys_ok = false, h_scores_ok = false, h_positions_ok = false;
     double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0, t_main = 0, t_reduce = 0;
     int score_launches = 0;
 };
@@ -306,13 +308,13 @@ template <int SIGMA, int K> constexpr int fast_cap()
     return 512;
 }
 
-template <int SIGMA, int K>
+template <int SIGMA, int K, bool POS = false>
 int launch_score(ipkgpu_ctx* ctx, const ScoreParams& p)
 {
     constexpr int CAP = fast_cap<SIGMA, K>();
     constexpr size_t lds = TileGeo<SIGMA, K, TW>::HEAD_BYTES + (size_t)NW * wave_scratch_entries<SIGMA, K, CAP>() * 8;
     static_assert(lds <= 160 * 1024, "fast-path LDS budget");
-    auto kern = score_tiles_kernel<SIGMA, K, CAP, TW, NW>;
+    auto kern = score_tiles_kernel<SIGMA, K, CAP, TW, NW, POS>;
     if (lds > 64 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t blocks = (uint64_t)p.n_batch_mats * p.tiles_per_mat;
@@ -322,7 +324,7 @@ int launch_score(ipkgpu_ctx* ctx, const ScoreParams& p)
     return IPKGPU_OK;
 }
 
-template <int SIGMA, int K>
+template <int SIGMA, int K, bool POS = false>
 int launch_overflow(ipkgpu_ctx* ctx, const ScoreParams& p)
 {
     if constexpr (Geo<SIGMA, K, 1 << 30>::DIRECT || ipow(SIGMA, K - K / 2) <= (uint32_t)fast_cap<SIGMA, K>()) {
@@ -331,7 +333,7 @@ int launch_overflow(ipkgpu_ctx* ctx, const ScoreParams& p)
     } else {
         constexpr size_t lds = TileGeo<SIGMA, K, 1>::HEAD_BYTES + (size_t)wave_scratch_entries<SIGMA, K, 1 << 30>() * 8;
         static_assert(lds <= 160 * 1024, "big-list LDS budget");
-        auto kern = score_overflow_kernel<SIGMA, K>;
+        auto kern = score_overflow_kernel<SIGMA, K, POS>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 64)));
@@ -481,6 +483,13 @@ int dispatch_stream_pass2(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t 
 #undef M_P2
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
 }
+int dispatch_score_pos(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScoreParams& p)
+{
+#define M_SP(S_, K_) do { int rc_ = launch_score<S_, K_, true>(ctx, p); return rc_ ? rc_ : launch_overflow<S_, K_, true>(ctx, p); } while (0)
+    IPK_DISPATCH(sigma, k, M_SP);
+#undef M_SP
+    return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+}
 int dispatch_overflow(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScoreParams& p)
 {
 #define M_OV(S_, K_) return launch_overflow<S_, K_>(ctx, p)
@@ -603,7 +612,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     p.mat_slot = ctx->idx.as<uint32_t>() + n_mats;
     p.n_batch_mats = nb; p.sites = pl.sites; p.nwin = pl.nwin; p.tiles_per_mat = pl.tiles_per_mat;
     p.eps = pl.eps;
-    p.table = ctx->table.as<uint32_t>();
+    p.table = ctx->table.p;
+    p.mat_rank = nullptr;
     p.table_size = pl.table_size;
     p.emitted = reinterpret_cast<unsigned long long*>(ctx->small);
     p.ovf_queue = ctx->ovfq.as<unsigned long long>();
@@ -890,6 +900,134 @@ int ipkgpu_score_groups(ipkgpu_ctx* ctx, const float* logp, uint32_t n_mats, uin
     return rc;
 }
 
+// ---- KEEP_POSITIONS variant -------------------------------------------
+int ipkgpu_score_groups_positions(ipkgpu_ctx* ctx, const float* logp, uint32_t n_mats, uint32_t sites, uint32_t sigma,
+                                  const uint32_t* mat_group, uint32_t k, float log_eps, ipkgpu_result** out)
+{
+    if (!ctx) return IPKGPU_ERR_INVALID;
+    if (!out) return fail(ctx, IPKGPU_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    Plan pl;
+    RC_TRY(make_plan(ctx, logp, n_mats, sites, sigma, mat_group, k, log_eps, pl));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((uint64_t)n_mats * pl.nwin >= 0xFFFFFFFFull) return fail(ctx, IPKGPU_ERR_INVALID, "too many windows per group for the position code");
+    pl.gpb = std::max<uint64_t>(1, pl.gpb / 2);                      // 8-byte table entries
+    const uint32_t n_groups = pl.n_groups, cpg = pl.chunks_per_group;
+
+    ipkgpu_result* res = new (std::nothrow) ipkgpu_result();
+    if (!res) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
+    res->ctx = ctx;
+    res->group_ids = pl.group_ids;
+    res->offsets.assign((size_t)n_groups + 1, 0);
+    struct Guard { ipkgpu_result* r; ~Guard() { if (r) ipkgpu_result_free(r); } } guard{res};
+
+    // host matrices in; rank of every matrix inside its group = processing order of explore_group (:641)
+    const size_t bytes = (size_t)n_mats * sites * sigma * 4;
+    float* d_logp = nullptr;
+    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&d_logp, std::max<size_t>(bytes, 4)));
+    struct LGuard { ipkgpu_ctx* c; void* p; ~LGuard() { ctx_release(c, p); } } lguard{ctx, d_logp};
+    HIP_TRY(ctx, hipMemcpy(d_logp, logp, bytes, hipMemcpyHostToDevice));
+    std::vector<uint32_t> rank(n_mats), seen(n_groups, 0);
+    for (uint32_t i = 0; i < n_mats; ++i) rank[i] = seen[pl.slot_of[i]]++;
+    RC_TRY(ensure(ctx, ctx->branch, (size_t)n_mats * 4));
+    HIP_TRY(ctx, hipMemcpy(ctx->branch.p, rank.data(), (size_t)n_mats * 4, hipMemcpyHostToDevice));
+
+    RC_TRY(ensure(ctx, ctx->counts, (size_t)(pl.gpb * cpg) * 4));
+    RC_TRY(ensure(ctx, ctx->offsets, (size_t)(pl.gpb * cpg + 1) * 8));
+    RC_TRY(ensure(ctx, ctx->goff, (size_t)(pl.gpb + 1) * 8));
+    ctx->acc_main_ms = ctx->acc_reduce_ms = 0;
+    Stopwatch sw(ctx->stream);
+    const int t_begin = sw.mark();
+    RC_TRY(run_prefix(ctx, pl, d_logp));
+    std::vector<uint32_t> idx_host((size_t)n_mats * 2);
+    uint64_t total_entries = 0;
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)pl.gpb) {
+        const uint32_t gb = std::min<uint32_t>((uint32_t)pl.gpb, n_groups - g0);
+        uint32_t nb = 0;
+        for (uint32_t i = 0; i < n_mats; ++i) {
+            idx_host[n_mats + i] = 0;
+            if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) { idx_host[nb++] = i; idx_host[n_mats + i] = pl.slot_of[i] - g0; }
+        }
+        RC_TRY(ensure(ctx, ctx->idx, (size_t)n_mats * 8));
+        RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 8));
+        RC_TRY(ensure(ctx, ctx->ovfq, (size_t)nb * pl.nwin * 8));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->idx.p, idx_host.data(), (size_t)n_mats * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ScoreParams p;
+        p.logp = d_logp; p.best = ctx->best.as<float>();
+        p.mat_list = ctx->idx.as<uint32_t>(); p.mat_slot = ctx->idx.as<uint32_t>() + n_mats;
+        p.n_batch_mats = nb; p.sites = sites; p.nwin = pl.nwin; p.tiles_per_mat = pl.tiles_per_mat; p.eps = log_eps;
+        p.table = ctx->table.p; p.table_size = pl.table_size; p.mat_rank = ctx->branch.as<uint32_t>();
+        p.emitted = reinterpret_cast<unsigned long long*>(ctx->small);
+        p.ovf_queue = ctx->ovfq.as<unsigned long long>();
+        p.ovf_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 16);
+        p.flags = 0;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->table.p, 0, (size_t)gb * pl.table_size * 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
+        RC_TRY(dispatch_score_pos(ctx, sigma, k, p));
+        res->score_launches += 1;
+        const uint32_t n_chunks = gb * cpg;
+        hipLaunchKernelGGL(count_chunks64_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream,
+                           ctx->table.as<unsigned long long>(), pl.table_size, cpg, ctx->counts.as<uint32_t>());
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                           ctx->counts.as<uint32_t>(), (uint64_t)n_chunks, total_entries, ctx->offsets.as<uint64_t>());
+        hipLaunchKernelGGL(gather_offsets_kernel, dim3((gb + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                           ctx->offsets.as<uint64_t>(), cpg, gb + 1, ctx->goff.as<uint64_t>());
+        HIP_TRY(ctx, hipGetLastError());
+        std::vector<uint64_t> goff((size_t)gb + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(goff.data(), ctx->goff.p, ((size_t)gb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t g = 0; g <= gb; ++g) res->offsets[g0 + g] = goff[g];
+        const uint64_t new_total = goff[gb];
+        if (new_total > res->cap) {
+            const size_t new_cap = (g0 + gb >= n_groups) ? (size_t)new_total : (size_t)std::max<uint64_t>(new_total, 2 * res->cap);
+            uint32_t *nk = nullptr, *np = nullptr; float* ns = nullptr;
+            HIP_TRY(ctx, ctx_alloc(ctx, (void**)&nk, std::max<size_t>(new_cap, 1) * 4));
+            hipError_t e2 = ctx_alloc(ctx, (void**)&ns, std::max<size_t>(new_cap, 1) * 4);
+            hipError_t e3 = e2 == hipSuccess ? ctx_alloc(ctx, (void**)&np, std::max<size_t>(new_cap, 1) * 4) : e2;
+            if (e3 != hipSuccess) { ctx_release(ctx, nk); ctx_release(ctx, ns); HIP_TRY(ctx, e3); }
+            if (total_entries) {
+                (void)hipMemcpyAsync(nk, res->d_keys, total_entries * 4, hipMemcpyDeviceToDevice, ctx->stream);
+                (void)hipMemcpyAsync(ns, res->d_scores, total_entries * 4, hipMemcpyDeviceToDevice, ctx->stream);
+                (void)hipMemcpyAsync(np, res->d_positions, total_entries * 4, hipMemcpyDeviceToDevice, ctx->stream);
+                (void)hipStreamSynchronize(ctx->stream);
+            }
+            ctx_release(ctx, res->d_keys); ctx_release(ctx, res->d_scores); ctx_release(ctx, res->d_positions);
+            res->d_keys = nk; res->d_scores = ns; res->d_positions = np; res->cap = new_cap;
+        }
+        if (sigma == 4)
+            hipLaunchKernelGGL(write_chunks_pos_kernel<4>, dim3(n_chunks), dim3(256), 0, ctx->stream, ctx->table.as<unsigned long long>(),
+                               pl.table_size, cpg, (int)k, pl.nwin, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores, res->d_positions);
+        else
+            hipLaunchKernelGGL(write_chunks_pos_kernel<20>, dim3(n_chunks), dim3(256), 0, ctx->stream, ctx->table.as<unsigned long long>(),
+                               pl.table_size, cpg, (int)k, pl.nwin, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores, res->d_positions);
+        HIP_TRY(ctx, hipGetLastError());
+        total_entries = new_total;
+    }
+    const int t_end = sw.mark();
+    unsigned long long emitted = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&emitted, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    res->emitted = emitted;
+    res->t_total = sw.ms(t_begin, t_end);
+    guard.r = nullptr;
+    *out = res;
+    return IPKGPU_OK;
+}
+
+const uint32_t* ipkgpu_result_positions(ipkgpu_result* r)
+{
+    if (!r || !r->d_positions) return nullptr;
+    if (!r->h_positions_ok) {
+        const size_t n = (size_t)r->offsets.back();
+        r->h_positions.resize(std::max<size_t>(n, 1));
+        (void)hipSetDevice(r->ctx->device);
+        if (n && hipMemcpy(r->h_positions.data(), r->d_positions, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+        r->h_positions_ok = true;
+    }
+    return r->h_positions.data();
+}
+
 uint32_t ipkgpu_result_num_groups(const ipkgpu_result* r) { return r ? (uint32_t)r->group_ids.size() : 0; }
 const uint32_t* ipkgpu_result_group_ids(const ipkgpu_result* r) { return r ? r->group_ids.data() : nullptr; }
 const uint64_t* ipkgpu_result_offsets(const ipkgpu_result* r) { return r ? r->offsets.data() : nullptr; }
@@ -941,7 +1079,7 @@ double ipkgpu_result_time_ms(const ipkgpu_result* r, int which)
 void ipkgpu_result_free(ipkgpu_result* r)
 {
     if (!r) return;
-    if (r->ctx) { (void)hipSetDevice(r->ctx->device); ctx_release(r->ctx, r->d_keys); ctx_release(r->ctx, r->d_scores); }
+    if (r->ctx) { (void)hipSetDevice(r->ctx->device); ctx_release(r->ctx, r->d_keys); ctx_release(r->ctx, r->d_scores); ctx_release(r->ctx, r->d_positions); }
     delete r;
 }
 

@@ -102,4 +102,55 @@ __global__ __launch_bounds__(256) void write_chunks_kernel(const uint32_t* __res
 }
 
 
+// ---- positions variant: 64-bit table (score code << 32 | ~sequence) -> keys, scores, positions -----
+__global__ __launch_bounds__(256) void count_chunks64_kernel(const unsigned long long* __restrict__ table, uint64_t table_size,
+                                                             uint32_t chunks_per_group, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t g = blockIdx.x / chunks_per_group, c = blockIdx.x - g * chunks_per_group;
+    const unsigned long long* t = table + (size_t)g * table_size;
+    const uint64_t s0 = (uint64_t)c * CHUNK;
+    const uint32_t n = (uint32_t)min((uint64_t)CHUNK, table_size - s0);
+    uint32_t cnt = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) cnt += (t[s0 + i] != 0ull);
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+template <int SIGMA>
+__global__ __launch_bounds__(256) void write_chunks_pos_kernel(const unsigned long long* __restrict__ table, uint64_t table_size,
+                                                               uint32_t chunks_per_group, int k, uint32_t nwin,
+                                                               const uint64_t* __restrict__ offsets, uint32_t* __restrict__ keys,
+                                                               float* __restrict__ scores, uint32_t* __restrict__ positions)
+{
+    __shared__ uint32_t wcnt[4];
+    const uint32_t g = blockIdx.x / chunks_per_group, c = blockIdx.x - g * chunks_per_group;
+    const unsigned long long* t = table + (size_t)g * table_size;
+    const uint64_t s0 = (uint64_t)c * CHUNK;
+    const uint32_t n = (uint32_t)min((uint64_t)CHUNK, table_size - s0);
+    uint64_t out = offsets[blockIdx.x];
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        unsigned long long v = 0;
+        if (i < n) v = t[s0 + i];
+        const uint64_t m = __ballot(v != 0ull);
+        if (lane_id() == 0) wcnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) { const uint32_t x = wcnt[q]; total += x; if (q < wave) before += x; }
+        if (v != 0ull) {
+            const uint64_t pos = out + before + mbcnt(m);
+            keys[pos] = pack_code<SIGMA>((uint32_t)(s0 + i), k);
+            scores[pos] = __uint_as_float(dec_score_bits((uint32_t)(v >> 32)));
+            positions[pos] = (0xFFFFFFFFu - (uint32_t)v) % nwin;      // window start inside its matrix (window::get_position)
+        }
+        out += total;
+        __syncthreads();
+    }
+}
+
 }  // namespace ipkgpu

@@ -62,27 +62,48 @@ struct ScoreParams {
     const uint32_t* mat_slot;     // [n_mats] table slot of each matrix within this batch
     uint32_t n_batch_mats, sites, nwin, tiles_per_mat;
     float eps;
-    uint32_t* table;              // [slots][table_size]
+    void* table;                  // [slots][table_size] u32 score codes; u64 (code << 32 | ~sequence) when positions are kept
     uint64_t table_size;
+    const uint32_t* mat_rank;     // [n_mats] rank of each matrix inside its group (positions variant only)
     unsigned long long* emitted;
     unsigned long long* ovf_queue; // (mat << 32 | window start) of windows whose lists overflowed
     uint32_t* ovf_count;
     uint32_t flags;               // bit 0 (diagnostic builds of bench only): skip the table update
 };
 
+// ipk::put (branch_group.cpp:88-101): keep the larger score; the first one wins ties.
+struct PutScore {
+    uint32_t* tab;
+    __device__ __forceinline__ void operator()(uint32_t idx, uint32_t score_bits) const
+    {
+        atomicMax(tab + idx, enc_score_bits(score_bits));
+    }
+};
+// KEEP_POSITIONS variant (branch_group.cpp:73-86, db_builder.cpp:655-662): the window position travels with
+// the score.  64-bit max over (score code << 32 | ~sequence), sequence = processing order of the window inside
+// its group (matrix rank * windows + start): larger score wins, equal scores keep the EARLIER window.
+struct PutScorePos {
+    unsigned long long* tab;
+    uint32_t inv_seq;
+    __device__ __forceinline__ void operator()(uint32_t idx, uint32_t score_bits) const
+    {
+        atomicMax(tab + idx, ((unsigned long long)enc_score_bits(score_bits) << 32) | (unsigned long long)inv_seq);
+    }
+};
+
 // One window: build both half lists, then the final filtered cross product goes straight into the
-// group's max table (ipk::put, branch_group.cpp:88-101).  Returns false if a list overflowed CAP
-// (nothing has been emitted for the window in that case).
-template <int SIGMA, int K, int CAP>
+// group's max table.  Returns false if a list overflowed CAP (nothing has been emitted for the window
+// in that case).
+template <int SIGMA, int K, int CAP, class Put>
 __device__ __forceinline__ bool score_window(const WinCtx& c, float eps, uint2* scratch,
-                                             uint32_t* __restrict__ tab, unsigned long long& emitted, bool no_put = false)
+                                             const Put& put, unsigned long long& emitted, bool no_put = false)
 {
     if constexpr (Geo<SIGMA, K, CAP>::DIRECT) {
         const uint32_t lane = lane_id();
         float s = 0.f;
         bool pass = false;
         if (lane < Geo<SIGMA, K, CAP>::FULL) pass = Direct<SIGMA, 0, K>::eval(c, eps, lane, s);
-        if (pass) atomicMax(tab + lane, enc_score_bits(__float_as_uint(s)));
+        if (pass && !no_put) put(lane, __float_as_uint(s));
         emitted += (uint32_t)__popcll(__ballot(pass));
         return true;
     } else {
@@ -95,7 +116,7 @@ __device__ __forceinline__ bool score_window(const WinCtx& c, float eps, uint2* 
         for_each_pair(L, nL, R, nR, [&](bool valid, uint2 a, uint2 b) {
             const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
             const bool pass = valid && (s > eps);                              // :91
-            if (pass && !no_put) atomicMax(tab + (a.x * mulR + b.x), enc_score_bits(__float_as_uint(s)));
+            if (pass && !no_put) put(a.x * mulR + b.x, __float_as_uint(s));
             cnt += (uint32_t)__popcll(__ballot(pass));
         });
         emitted += cnt;
@@ -113,7 +134,7 @@ struct TileGeo {
 
 // Fast path: a workgroup stages the columns of TW consecutive windows of one matrix in LDS
 // (coalesced 16-byte loads), its NW wavefronts take windows round-robin.
-template <int SIGMA, int K, int CAP, int TW, int NW>
+template <int SIGMA, int K, int CAP, int TW, int NW, bool POS = false>
 __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -142,11 +163,20 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
 
     const uint32_t wave = threadIdx.x >> 6;
     uint2* scratch = scratch_all + (size_t)wave * WS;
-    uint32_t* tab = p.table + (size_t)p.mat_slot[mat] * p.table_size;
+    const size_t tab_off = (size_t)p.mat_slot[mat] * p.table_size;
     unsigned long long emitted = 0;                     // per-wave count of scored phylo-k-mers (can pass 2^32 on flat data)
     for (uint32_t w = wave; w < nw; w += NW) {
         WinCtx c{cols, best, w};
-        if (!score_window<SIGMA, K, CAP>(c, p.eps, scratch, tab, emitted, (p.flags & 1u) != 0)) {
+        bool ok;
+        if constexpr (POS) {
+            const PutScorePos put{reinterpret_cast<unsigned long long*>(p.table) + tab_off,
+                                  0xFFFFFFFFu - (p.mat_rank[mat] * p.nwin + t0 + w)};
+            ok = score_window<SIGMA, K, CAP>(c, p.eps, scratch, put, emitted, (p.flags & 1u) != 0);
+        } else {
+            const PutScore put{reinterpret_cast<uint32_t*>(p.table) + tab_off};
+            ok = score_window<SIGMA, K, CAP>(c, p.eps, scratch, put, emitted, (p.flags & 1u) != 0);
+        }
+        if (!ok) {
             if (lane_id() == 0) {
                 const uint32_t q = atomicAdd(p.ovf_count, 1u);
                 p.ovf_queue[q] = ((unsigned long long)mat << 32) | (unsigned long long)(t0 + w);
@@ -163,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
 // reaches the loop exit: the queue length is fixed before this kernel starts.
 constexpr int OVF_NW = 8;
 
-template <int SIGMA, int K>
+template <int SIGMA, int K, bool POS = false>
 __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -186,7 +216,10 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
         const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + start;
         for (uint32_t i = threadIdx.x; i <= K; i += OVF_NW * 64) best[i] = bsrc[i];
         __syncthreads();
-        uint32_t* tab = p.table + (size_t)p.mat_slot[mat] * p.table_size;
+        const size_t tab_off = (size_t)p.mat_slot[mat] * p.table_size;
+        uint32_t* tab = reinterpret_cast<uint32_t*>(p.table) + tab_off;
+        unsigned long long* tab64 = reinterpret_cast<unsigned long long*>(p.table) + tab_off;
+        const uint32_t inv_seq = POS ? 0xFFFFFFFFu - (p.mat_rank[mat] * p.nwin + start) : 0u;
         const uint2 *L = scratch, *R = scratch + Geo<SIGMA, K / 2, CAPF>::CAPH;
         if (wave == 0) {
             WinCtx c{cols, best, 0};
@@ -208,7 +241,10 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
                 if (valid) b = R[j];
                 const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
                 const bool pass = valid && (s > p.eps);                            // :91
-                if (pass && !(p.flags & 1u)) atomicMax(tab + (a.x * mulR + b.x), enc_score_bits(__float_as_uint(s)));
+                if (pass && !(p.flags & 1u)) {
+                    if constexpr (POS) PutScorePos{tab64, inv_seq}(a.x * mulR + b.x, __float_as_uint(s));
+                    else PutScore{tab}(a.x * mulR + b.x, __float_as_uint(s));
+                }
                 cnt += (uint32_t)__popcll(__ballot(pass));
             }
         }

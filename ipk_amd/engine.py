@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "ipkgpu_result_num_groups", "ipkgpu_result_group_ids", "ipkgpu_result_offsets",
     "ipkgpu_result_emitted", "ipkgpu_result_keys", "ipkgpu_result_scores",
     "ipkgpu_result_keys_device", "ipkgpu_result_scores_device", "ipkgpu_result_time_ms",
-    "ipkgpu_result_free",
+    "ipkgpu_result_free", "ipkgpu_score_groups_positions", "ipkgpu_result_positions",
 ]
 
 
@@ -91,6 +91,10 @@ def load_library():
     L.ipkgpu_result_time_ms.argtypes = [C.c_void_p, C.c_int]
     L.ipkgpu_result_free.restype = None
     L.ipkgpu_result_free.argtypes = [C.c_void_p]
+    L.ipkgpu_score_groups_positions.restype = C.c_int
+    L.ipkgpu_score_groups_positions.argtypes = L.ipkgpu_score_groups.argtypes
+    L.ipkgpu_result_positions.restype = u32p
+    L.ipkgpu_result_positions.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -150,6 +154,16 @@ class Result:
         p = self._lib.ipkgpu_result_scores(self._h)
         if not p:
             raise IpkGpuError(2, "device-to-host copy of scores failed")
+        return np.ctypeslib.as_array(p, shape=(n,))
+
+    def positions(self):
+        """Window positions aligned with keys()/scores() (KEEP_POSITIONS results only)."""
+        n = self.num_entries
+        if n == 0:
+            return np.zeros(0, np.uint32)
+        p = self._lib.ipkgpu_result_positions(self._h)
+        if not p:
+            raise IpkGpuError(1, "this result carries no positions")
         return np.ctypeslib.as_array(p, shape=(n,))
 
     def keys_device_ptr(self):
@@ -219,6 +233,21 @@ class Engine:
                 raise ValueError("mat_group must have one branch id per matrix")
             rc = self._lib.ipkgpu_score_groups_device(self._h, C.c_void_p(ptr), n_mats, sites, sigma,
                                                       gp, k, C.c_float(log_eps), C.byref(out))
+        if rc != 0:
+            raise self._err(rc)
+        return Result(self._lib, out)
+
+    def score_groups_positions(self, logp, mat_group, k, log_eps):
+        """KEEP_POSITIONS flavour (ipk-aa-pos): logp numpy float32 [n_mats, sites, sigma]; Result.positions()."""
+        logp = np.ascontiguousarray(logp, dtype=np.float32)
+        mat_group = np.ascontiguousarray(mat_group, dtype=np.uint32)
+        n_mats, sites, sigma = logp.shape
+        if mat_group.shape != (n_mats,):
+            raise ValueError("mat_group must have one branch id per matrix")
+        out = C.c_void_p()
+        rc = self._lib.ipkgpu_score_groups_positions(self._h, logp.ctypes.data_as(C.c_void_p), n_mats, sites, sigma,
+                                                     mat_group.ctypes.data_as(C.POINTER(C.c_uint32)), k, C.c_float(log_eps),
+                                                     C.byref(out))
         if rc != 0:
             raise self._err(rc)
         return Result(self._lib, out)

@@ -336,3 +336,72 @@ void ipko_log10f(const float* in, size_t n, float* out)
 {
     for (size_t i = 0; i < n; ++i) out[i] = log10f(in[i]);
 }
+
+/* ---------------------------------------------------------------------------------------
+ * KEEP_POSITIONS flavour of explore_group (db_builder.cpp:655-662,687-689) with the positions
+ * variant of put (branch_group.cpp:73-86): the map value is {score, position}; an existing entry is
+ * replaced only when its score is strictly smaller, so on equal scores the first window (matrices in
+ * order, windows by ascending start) keeps its position.  position = window.get_position() = start.
+ * ------------------------------------------------------------------------------------- */
+typedef struct { uint32_t key; float score; uint32_t pos; } pkp_t;
+typedef struct ipko_group_pos { pkp_t* v; size_t n; uint64_t emitted; } ipko_group_pos;
+
+static int cmp_keyp_asc(const void* a, const void* b)
+{
+    uint32_t x = ((const pkp_t*)a)->key, y = ((const pkp_t*)b)->key;
+    return (x > y) - (x < y);
+}
+
+ipko_group_pos* ipko_explore_group_pos(const float* mats, size_t n_mats, size_t sites, unsigned sigma,
+                                       unsigned k, float eps)
+{
+    ipko_group_pos* g = (ipko_group_pos*)calloc(1, sizeof(ipko_group_pos));
+    size_t cap = 1024, n = 0;
+    uint32_t* keys = (uint32_t*)malloc(cap * 4); float* vals = (float*)malloc(cap * 4);
+    uint32_t* poss = (uint32_t*)malloc(cap * 4); uint8_t* used = (uint8_t*)calloc(cap, 1);
+    float* best = (float*)malloc((sites + 1) * sizeof(float));
+    const unsigned bits = ipko_bits(sigma);
+    for (size_t q = 0; q < n_mats; ++q) {
+        const float* m = mats + q * sites * sigma;
+        ipko_prefix_max(m, sites, sigma, best);
+        for (size_t start = 0; start + k <= sites; ++start) {
+            win_t w = { m, best, sigma, bits, start };
+            vec_t r = dc(&w, 0, k, eps);
+            for (size_t e = 0; e < r.n; ++e) {
+                if ((n + 1) * 2 > cap) {                          /* grow + rehash */
+                    size_t ncap = cap * 2;
+                    uint32_t* nk = (uint32_t*)malloc(ncap * 4); float* nv = (float*)malloc(ncap * 4);
+                    uint32_t* np = (uint32_t*)malloc(ncap * 4); uint8_t* nu = (uint8_t*)calloc(ncap, 1);
+                    for (size_t i = 0; i < cap; ++i) if (used[i]) {
+                        size_t j = mix32(keys[i]) & (ncap - 1);
+                        while (nu[j]) j = (j + 1) & (ncap - 1);
+                        nu[j] = 1; nk[j] = keys[i]; nv[j] = vals[i]; np[j] = poss[i];
+                    }
+                    free(keys); free(vals); free(poss); free(used);
+                    keys = nk; vals = nv; poss = np; used = nu; cap = ncap;
+                }
+                size_t i = mix32(r.v[e].key) & (cap - 1);
+                while (used[i] && keys[i] != r.v[e].key) i = (i + 1) & (cap - 1);
+                if (used[i]) {
+                    if (vals[i] < r.v[e].score) { vals[i] = r.v[e].score; poss[i] = (uint32_t)start; }   /* :77-80 */
+                } else { used[i] = 1; keys[i] = r.v[e].key; vals[i] = r.v[e].score; poss[i] = (uint32_t)start; ++n; }
+            }
+            g->emitted += r.n;
+            free(r.v);
+        }
+    }
+    g->n = n;
+    g->v = (pkp_t*)malloc((n ? n : 1) * sizeof(pkp_t));
+    size_t o = 0;
+    for (size_t i = 0; i < cap; ++i) if (used[i]) { g->v[o].key = keys[i]; g->v[o].score = vals[i]; g->v[o].pos = poss[i]; ++o; }
+    qsort(g->v, g->n, sizeof(pkp_t), cmp_keyp_asc);
+    free(keys); free(vals); free(poss); free(used); free(best);
+    return g;
+}
+size_t ipko_group_pos_size(const ipko_group_pos* g) { return g->n; }
+uint64_t ipko_group_pos_emitted(const ipko_group_pos* g) { return g->emitted; }
+void ipko_group_pos_copy(const ipko_group_pos* g, uint32_t* keys, float* scores, uint32_t* pos)
+{
+    for (size_t i = 0; i < g->n; ++i) { keys[i] = g->v[i].key; scores[i] = g->v[i].score; pos[i] = g->v[i].pos; }
+}
+void ipko_group_pos_free(ipko_group_pos* g) { if (g) { free(g->v); free(g); } }

@@ -57,6 +57,16 @@ def lib():
         L.ipko_explore_many.restype = C.c_uint64
         L.ipko_explore_many.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint,
                                         C.c_float, C.POINTER(C.c_uint64)]
+        L.ipko_explore_group_pos.restype = C.c_void_p
+        L.ipko_explore_group_pos.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint, C.c_float]
+        L.ipko_group_pos_size.restype = C.c_size_t
+        L.ipko_group_pos_size.argtypes = [C.c_void_p]
+        L.ipko_group_pos_emitted.restype = C.c_uint64
+        L.ipko_group_pos_emitted.argtypes = [C.c_void_p]
+        L.ipko_group_pos_copy.restype = None
+        L.ipko_group_pos_copy.argtypes = [C.c_void_p, u32p, f32p, u32p]
+        L.ipko_group_pos_free.restype = None
+        L.ipko_group_pos_free.argtypes = [C.c_void_p]
         L.ipko_log10f.restype = None
         L.ipko_log10f.argtypes = [f32p, C.c_size_t, f32p]
         _lib = L
@@ -155,3 +165,20 @@ def log10f(a):
     out = np.empty_like(a)
     lib().ipko_log10f(ap, a.size, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+def explore_group_pos(mats, k, eps):
+    """KEEP_POSITIONS flavour: (keys sorted, scores, positions, emitted)."""
+    mats, mp = _f32(mats)
+    n_mats, sites, sigma = mats.shape
+    L = lib()
+    g = L.ipko_explore_group_pos(mp, n_mats, sites, sigma, k, C.c_float(eps))
+    try:
+        n = L.ipko_group_pos_size(g)
+        keys = np.empty(n, dtype=np.uint32); scores = np.empty(n, dtype=np.float32); pos = np.empty(n, dtype=np.uint32)
+        L.ipko_group_pos_copy(g, keys.ctypes.data_as(C.POINTER(C.c_uint32)), scores.ctypes.data_as(C.POINTER(C.c_float)),
+                              pos.ctypes.data_as(C.POINTER(C.c_uint32)))
+        emitted = int(L.ipko_group_pos_emitted(g))
+    finally:
+        L.ipko_group_pos_free(g)
+    return keys, scores, pos, emitted

@@ -70,3 +70,19 @@ def explore_group(mats, k, eps, bits):
     keys = np.array(sorted(table), dtype=np.uint32)
     scores = np.array([table[int(x)] for x in keys], dtype=f32)
     return keys, scores, emitted
+
+
+def explore_group_pos(mats, k, eps, bits):
+    """KEEP_POSITIONS flavour (branch_group.cpp:73-86): first window wins ties; returns positions too."""
+    table = {}
+    for m in mats:
+        m = np.asarray(m, dtype=f32)
+        best = prefix_max(m)
+        for start in range(0, m.shape[0] - k + 1):
+            keys, scores = window(m, k, start, eps, bits, best)
+            for key, s in zip(keys.tolist(), scores.tolist()):
+                old = table.get(key)
+                if old is None or old[0] < s:
+                    table[key] = (s, start)
+    keys = np.array(sorted(table), dtype=np.uint32)
+    return keys, np.array([table[int(x)][0] for x in keys], dtype=f32), np.array([table[int(x)][1] for x in keys], dtype=np.uint32)

@@ -191,3 +191,31 @@ def test_v1_variant_still_matches(engine):
         check_against_oracle(engine, mats, [0, 0, 1, 1], 10, co.log_threshold(1.5, 4, 10))
     finally:
         engine.set_option("variant", 0)
+
+
+@pytest.mark.parametrize("sigma,k,sites", [(4, 8, 90), (4, 10, 150), (20, 3, 30), (20, 6, 14)])
+def test_keep_positions_variant(engine, sigma, k, sites):
+    """Row a11 (ipk-aa-pos): kept score + position of the FIRST window reaching it."""
+    mats = synth_matrices(5, sites, sigma, 0.1, 70 + k)
+    groups = np.array([4, 9, 4, 9, 2], dtype=np.uint32)          # interleaved matrices, one single-matrix group
+    eps = co.log_threshold(1.5, sigma, k)
+    res = engine.score_groups_positions(mats, groups, k, eps)
+    assert res.group_ids.tolist() == [4, 9, 2]
+    tot = 0
+    for gi, gid in enumerate([4, 9, 2]):
+        keys, scores, pos, emitted = co.explore_group_pos(mats[groups == gid], k, eps)
+        a, b = int(res.offsets[gi]), int(res.offsets[gi + 1])
+        assert np.array_equal(res.keys()[a:b], keys)
+        assert np.array_equal(res.scores()[a:b].view(np.uint32), scores.view(np.uint32))
+        assert np.array_equal(res.positions()[a:b], pos)
+        tot += emitted
+    assert res.emitted == tot
+    res.free()
+
+
+def test_keep_positions_ties_keep_first_window(engine):
+    col = np.log10(np.array([0.4, 0.3, 0.2, 0.1], dtype=np.float32))
+    mats = np.tile(col, (2, 25, 1)).astype(np.float32)           # every window scores every k-mer identically
+    res = engine.score_groups_positions(mats, [0, 0], 6, co.log_threshold(1.0, 4, 6))
+    assert res.num_entries > 0 and np.all(res.positions() == 0)  # first window of the first matrix wins every tie
+    res.free()

@@ -86,3 +86,15 @@ def test_mif0_matches_direct_formula():
     h = lambda x: -x * np.log2(x)
     H = N * h(float(thr) / S) + sum(h(x / S) - h(float(thr) / S) for x in s)
     assert abs(co.mif0(ls, N, float(thr)) - S * (H - np.log2(N))) < 1e-12
+
+
+@pytest.mark.parametrize("sigma,k", [(4, 5), (20, 2)])
+def test_positions_oracle_pair(sigma, k):
+    m = synth_matrices(2, 30, sigma, 0.2, 9)
+    eps = co.log_threshold(1.5, sigma, k)
+    k1, s1, p1, _ = co.explore_group_pos(m, k, eps)
+    k2, s2, p2 = no.explore_group_pos(m, k, eps, co.bits(sigma))
+    assert np.array_equal(k1, k2) and np.array_equal(s1.view(np.uint32), s2.view(np.uint32)) and np.array_equal(p1, p2)
+    # positions never change the (key, score) set
+    k0, s0, _ = co.explore_group(m, k, eps)
+    assert np.array_equal(k0, k1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
