@@ -219,3 +219,50 @@ def test_keep_positions_ties_keep_first_window(engine):
     res = engine.score_groups_positions(mats, [0, 0], 6, co.log_threshold(1.0, 4, 6))
     assert res.num_entries > 0 and np.all(res.positions() == 0)  # first window of the first matrix wins every tie
     res.free()
+
+
+def test_randomised_small_cases(engine):
+    """Many random small configurations (alphabet, k, shape, grouping, threshold, zero probabilities) in one
+    process: group-major sets, scored counts and the key-major database against the oracle, bit for bit."""
+    from ipk_amd import distributed as D
+    from oracle import db_oracle as dbo
+    rng = np.random.default_rng(20261003)
+    n_cases = 60
+    for case in range(n_cases):
+        sigma = 4 if rng.random() < 0.65 else 20
+        k = int(rng.integers(2, 11)) if sigma == 4 else int(rng.integers(2, 5))
+        sites = int(rng.integers(k, k + 40))
+        n_mats = int(rng.integers(1, 7))
+        alpha = float(rng.choice([0.03, 0.1, 0.3, 1.0]))
+        mats = synth_matrices(n_mats, sites, sigma, alpha, int(rng.integers(1, 10 ** 6)))
+        if rng.random() < 0.3:                                    # sprinkle log10(0)
+            idx = rng.integers(0, mats.size, size=3)
+            mats.reshape(-1)[idx] = -np.inf
+        groups = rng.integers(0, max(1, n_mats // 2 + 1), size=n_mats).astype(np.uint32) * 11 + 3
+        omega = float(rng.choice([1.0, 1.5, 2.0]))
+        eps = co.log_threshold(omega, sigma, k) + float(rng.choice([0.0, -1.0, 0.5]))
+        order = list(dict.fromkeys(groups.tolist()))
+        res = engine.score_groups(mats, groups, k, eps)
+        assert res.group_ids.tolist() == order, case
+        ref, emitted = [], 0
+        for gi, gid in enumerate(order):
+            keys, scores, e = co.explore_group(mats[groups == gid], k, eps)
+            gk, gs = res.group(gi)
+            assert np.array_equal(gk, keys) and np.array_equal(gs.view(np.uint32), scores.view(np.uint32)), (case, sigma, k, sites)
+            ref.append((gid, keys, scores)); emitted += e
+        assert res.emitted == emitted, case
+        res.free()
+        if case % 3 == 0:
+            world = int(rng.integers(1, 4))
+            parts = engine.score_groups_keymajor(mats, groups, k, eps, n_owners=world)
+            full = dbo.build_db(ref)
+            for o in range(world):
+                a, b = int(parts.owner_offsets[o]), int(parts.owner_offsets[o + 1])
+                db = engine.merge_parts(sigma, k, o, world, parts.counts_tensor()[o:o + 1].contiguous(),
+                                        parts.entries_tensor()[a:b].contiguous(), np.zeros(1, np.uint64))
+                keys, off, br, sc = dbo.db_shard_arrays(full, sigma, k, o, world)
+                bb, ss = db.entries()
+                assert np.array_equal(db.keys(), keys) and np.array_equal(db.key_offsets(), off), case
+                assert np.array_equal(bb, br) and np.array_equal(ss.view(np.uint32), sc), case
+                db.free()
+            parts.free()
