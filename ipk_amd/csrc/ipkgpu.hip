@@ -391,6 +391,28 @@ int launch_stream_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
 }
 
 template <int SIGMA, int K>
+int launch_stream_overflow(ipkgpu_ctx* ctx, const StreamParams& sp)
+{
+    constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
+    if constexpr (TBL == 0 || ipow(SIGMA, K - K / 2) <= (uint32_t)fast_cap<SIGMA, K>()) {
+        (void)ctx; (void)sp;
+        return IPKGPU_OK;                           // lists can never overflow
+    } else {
+        constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+        constexpr size_t lds = TileGeo<SIGMA, K, 1>::HEAD_BYTES + (size_t)wave_scratch_entries<SIGMA, K, 1 << 30>() * 8 +
+                               (size_t)OVF_NW * 2 * NB * SUB * 4;
+        static_assert(lds + 64 <= 160 * 1024, "big-list (stream) LDS budget");
+        auto kern = score_overflow_stream_kernel<SIGMA, K, TBL>;
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 64)));
+        hipLaunchKernelGGL(kern, dim3(ctx->num_cu * per_cu), dim3(OVF_NW * 64), lds, ctx->stream, sp);
+        HIP_TRY(ctx, hipGetLastError());
+        return IPKGPU_OK;
+    }
+}
+
+template <int SIGMA, int K>
 int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* table)
 {
     constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
@@ -488,6 +510,13 @@ int dispatch_score_pos(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScoreP
 #define M_SP(S_, K_) do { int rc_ = launch_score<S_, K_, true>(ctx, p); return rc_ ? rc_ : launch_overflow<S_, K_, true>(ctx, p); } while (0)
     IPK_DISPATCH(sigma, k, M_SP);
 #undef M_SP
+    return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+}
+int dispatch_stream_overflow(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const StreamParams& sp)
+{
+#define M_SO(S_, K_) return launch_stream_overflow<S_, K_>(ctx, sp)
+    IPK_DISPATCH(sigma, k, M_SO);
+#undef M_SO
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
 }
 int dispatch_overflow(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScoreParams& p)
@@ -675,7 +704,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     // An existing pool is kept as long as it covers the expectation without the margin -- regrowing a multi-GB
     // buffer costs hundreds of ms, and an underestimate is caught by the redo path anyway.
     const double ppw = ctx->pairs_per_window > 0 ? ctx->pairs_per_window : 256.0;
-    const uint64_t slack = 2 * n_waves * NBK * SUB + n_waves * ALLOC_BATCH + 1024;
+    const uint64_t ovf_waves = (uint64_t)ctx->num_cu * 4 * OVF_NW;          // big-list kernel: its waves hold open chunks too
+    const uint64_t slack = 2 * (n_waves + ovf_waves) * NBK * SUB + (n_waves + ovf_waves) * ALLOC_BATCH + 1024;
     uint64_t want = (uint64_t)((double)windows * ppw * 1.25 / CH) + slack;
     {
         const uint64_t have = std::min<uint64_t>(ctx->pool.cap / (CH * 8), ctx->desc.cap / 8);
@@ -706,18 +736,42 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         sp.eps = pl.eps;
         sp.pool = ctx->pool.as<uint2>(); sp.pool_cap = (uint32_t)cap; sp.pool_next = d_pool_next;
         sp.desc = ctx->desc.as<unsigned long long>(); sp.pool_ovf = d_pool_ovf;
-        sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count;
+        sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot;
         sp.flags = ctx->opt_variant == 0 ? 0u : (uint32_t)(ctx->opt_flags);
         Stopwatch sw(ctx->stream);
         const int ev_a = sw.mark();
         RC_TRY(dispatch_stream_pass1(ctx, pl.sigma, pl.k, sp, n_wg));
         const int ev_b = sw.mark();
+        // windows whose half lists overflowed the fast path: big-list kernel.  With the queue sorted by group it
+        // appends to the same pool (LDS max-reduce in pass 2); otherwise (field widths exceeded) it falls back to
+        // global atomics on the finished tables after pass 2.
+        uint32_t n_ovf = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&n_ovf, p.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const bool ovf_in_pool = n_ovf > 0 && gb < (1u << 22) && n_mats < (1u << 21) && pl.nwin < (1u << 21);
+        if (ovf_in_pool) {
+            RC_TRY(ensure(ctx, ctx->tmp_a, (size_t)n_ovf * 8));
+            RC_TRY(ensure(ctx, ctx->tmp_b, (size_t)n_ovf * 8));
+            hipLaunchKernelGGL(ovf_group_keys_kernel, dim3((n_ovf + 255) / 256), dim3(256), 0, ctx->stream,
+                               p.ovf_queue, n_ovf, p.mat_slot, ctx->tmp_a.as<unsigned long long>());
+            HIP_TRY(ctx, hipGetLastError());
+            size_t tmp_bytes = 0;
+            HIP_TRY(ctx, rocprim::radix_sort_keys(nullptr, tmp_bytes, ctx->tmp_a.as<unsigned long long>(), ctx->tmp_b.as<unsigned long long>(),
+                                                  (size_t)n_ovf, 0, 64, ctx->stream));
+            RC_TRY(ensure(ctx, ctx->tmp_c, tmp_bytes));
+            HIP_TRY(ctx, rocprim::radix_sort_keys(ctx->tmp_c.p, tmp_bytes, ctx->tmp_a.as<unsigned long long>(), ctx->tmp_b.as<unsigned long long>(),
+                                                  (size_t)n_ovf, 0, 64, ctx->stream));
+            StreamParams so = sp;
+            so.ovf_queue = ctx->tmp_b.as<unsigned long long>();
+            RC_TRY(dispatch_stream_overflow(ctx, pl.sigma, pl.k, so));
+        }
         uint32_t h[2] = {0, 0};
         HIP_TRY(ctx, hipMemcpyAsync(h, d_pool_next, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (h[1] != 0) {                    // pool exhausted: h[0] chunks were asked for
             if (cap >= max_chunks) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool exhausted at the device-memory limit (lower workspace_bytes to score fewer groups per batch)");
-            want = (uint64_t)((double)h[0] * 1.1) + 1024;
+            // (h[0] = ids drawn is no measure of the need: an exhausted pool is asked again at every append)
+            want = std::max<uint64_t>(cap * 2, want);
             continue;
         }
         const uint32_t n_used = (uint32_t)std::min<uint64_t>(h[0], cap);
@@ -742,8 +796,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         const int ev_c = sw.mark();
         RC_TRY(dispatch_stream_pass2(ctx, pl.sigma, pl.k, (uint32_t)n_gb, pl.table_size, ctx->table.as<uint32_t>()));
         const int ev_d = sw.mark();
-        // windows whose half lists overflowed the fast path: big-list kernel, max-reduced into the finished tables
-        RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
+        if (n_ovf > 0 && !ovf_in_pool) RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->acc_main_ms += sw.ms(ev_a, ev_b);
         ctx->acc_reduce_ms += sw.ms(ev_c, ev_d);

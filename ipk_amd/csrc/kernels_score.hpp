@@ -286,6 +286,7 @@ struct StreamParams {
     unsigned long long* emitted;
     unsigned long long* ovf_queue;
     uint32_t* ovf_count;
+    const uint32_t* mat_slot;      // [n_mats] group slot of a matrix inside the batch (big-list kernel)
     uint32_t flags;                // diagnostics: bit 0 = skip the pool stores, bit 1 = skip the append bookkeeping too
 };
 
@@ -567,6 +568,101 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void 
         if (id != CHUNK_NONE) p.desc[id] = ((unsigned long long)(g * NB + b / SUB) << 32) | (unsigned long long)min(cfill[b], CH);
     }
     if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);
+}
+
+// Big-list windows of the stream variant: same cooperative shape as score_overflow_kernel (wave 0 builds
+// the half lists at worst-case capacity, all waves share the final cross product), but the survivors are
+// appended to the pair pool like everything else, so they are max-reduced in LDS by pass 2 instead of by
+// global atomics.  Runs between pass 1 and the chunk index.  A wave keeps its chunks open while
+// consecutive queue entries belong to the same group.
+template <int SIGMA, int K, uint32_t TBL>
+__global__ __launch_bounds__(OVF_NW * 64) void score_overflow_stream_kernel(StreamParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int CAPF = 1 << 30;
+    constexpr uint32_t T = ipow(SIGMA, K);
+    constexpr uint32_t NB = (T + TBL - 1) / TBL;
+    using TG = TileGeo<SIGMA, K, 1>;
+    __shared__ uint32_t sh_n[2];
+    float* cols = reinterpret_cast<float*>(smem);
+    float* best = cols + TG::COLS_F;
+    uint2* scratch = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
+    uint32_t* state_all = reinterpret_cast<uint32_t*>(scratch + wave_scratch_entries<SIGMA, K, CAPF>());
+    const uint32_t n = *p.ovf_count;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t* cbase = state_all + (size_t)wave * 2 * NB * SUB;
+    uint32_t* cfill = cbase + NB * SUB;
+    for (uint32_t b = lane; b < NB * SUB; b += 64) { cbase[b] = CHUNK_NONE; cfill[b] = CH; }
+    Appender<TBL, NB> app{p, cbase, cfill, 0u};
+    bool have_group = false;
+    unsigned long long emitted = 0;
+    constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
+    auto close_chunks = [&]() {
+        wave_lds_sync();
+        for (uint32_t b = lane; b < NB * SUB; b += 64) {
+            const uint32_t id = cbase[b];
+            if (id != CHUNK_NONE) p.desc[id] = ((unsigned long long)(app.g * NB + b / SUB) << 32) | (unsigned long long)min(cfill[b], CH);
+            cbase[b] = CHUNK_NONE; cfill[b] = CH;
+        }
+        wave_lds_sync();
+    };
+    // the queue arrives sorted by group (ovf_group_keys_kernel + radix sort); each workgroup takes one contiguous
+    // block of it, so a wave's open chunks are closed only at the few group boundaries inside its block
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t q_lo = min(n, blockIdx.x * per), q_hi = min(n, q_lo + per);
+    for (uint32_t q = q_lo; q < q_hi; ++q) {
+        const unsigned long long e = p.ovf_queue[q];
+        const uint32_t g = (uint32_t)(e >> 42), mat = (uint32_t)(e >> 21) & 0x1FFFFFu, start = (uint32_t)e & 0x1FFFFFu;
+        if (have_group && g != app.g) close_chunks();
+        app.g = g; have_group = true;
+        __syncthreads();                                                       // previous window's lists consumed
+        const float* src = p.logp + ((size_t)mat * p.sites + start) * SIGMA;
+        for (uint32_t i = threadIdx.x; i < K * SIGMA; i += OVF_NW * 64) cols[i] = src[i];
+        const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + start;
+        for (uint32_t i = threadIdx.x; i <= K; i += OVF_NW * 64) best[i] = bsrc[i];
+        __syncthreads();
+        const uint2 *L = scratch, *R = scratch + Geo<SIGMA, K / 2, CAPF>::CAPH;
+        if (wave == 0) {
+            WinCtx c{cols, best, 0};
+            uint32_t nL = 0, nR = 0;
+            build_halves<SIGMA, K, CAPF>(c, p.eps, scratch, L, nL, R, nR);      // cannot overflow at full capacity
+            if (lane == 0) { sh_n[0] = nL; sh_n[1] = nR; }
+        }
+        __syncthreads();
+        const uint32_t nL = sh_n[0], nR = sh_n[1];
+        if (nL == 0 || nR == 0) continue;
+        uint32_t cnt = 0;
+        for (uint32_t i = wave; i < nL; i += OVF_NW) {                         // rows of L dealt to the waves
+            const uint2 a = L[i];
+            for (uint32_t jb = 0; jb < nR; jb += 128) {
+                const uint32_t ja = jb + lane, jc = jb + 64 + lane;
+                const bool va = ja < nR, vb = jc < nR;
+                uint2 b0 = make_uint2(0, 0), b1 = b0;
+                if (va) b0 = R[ja];
+                if (vb) b1 = R[jc];
+                const float s0 = __uint_as_float(a.y) + __uint_as_float(b0.y);   // pk_compute.cpp:90
+                const float s1 = __uint_as_float(a.y) + __uint_as_float(b1.y);
+                const bool p0 = va && (s0 > p.eps), p1 = vb && (s1 > p.eps);      // :91
+                cnt += (uint32_t)__popcll(__ballot(p0)) + (uint32_t)__popcll(__ballot(p1));
+                app.append2(p0, a.x * mulR + b0.x, __float_as_uint(s0), p1, a.x * mulR + b1.x, __float_as_uint(s1));
+            }
+        }
+        emitted += cnt;
+    }
+    if (have_group) close_chunks();
+    if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);
+}
+
+// (mat << 32 | start) -> (group << 42 | mat << 21 | start): sortable by group (host checks the field widths)
+__global__ __launch_bounds__(256) void ovf_group_keys_kernel(const unsigned long long* __restrict__ queue, uint32_t n,
+                                                             const uint32_t* __restrict__ mat_slot,
+                                                             unsigned long long* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long e = queue[i];
+    const uint32_t mat = (uint32_t)(e >> 32), start = (uint32_t)e;
+    out[i] = ((unsigned long long)mat_slot[mat] << 42) | ((unsigned long long)mat << 21) | (unsigned long long)start;
 }
 
 // chunk index: how many chunks each (group, bucket) has; then chunk ids grouped by (group, bucket)
