@@ -185,7 +185,12 @@ def main():
             if args.cpu_groups < 0:
                 n_cpu = int(max(2, min(ng, 15.0 / max(tp, 1e-3))))
             sample = synth_matrices(n_cpu * mpg, sites, sigma, cfg["alpha"], cfg["seed"], first_mat=0)
-            tc = time.perf_counter(); e_cpu, _ = co.explore_many(sample, mpg, k, eps); tc = time.perf_counter() - tc
+            tc = time.perf_counter(); e_cpu, u_cpu = co.explore_many(sample, mpg, k, eps); tc = time.perf_counter() - tc
+            # the same sample through the GPU path: scored count and unique (branch, k-mer) entries must agree
+            rs = eng.score_groups(sample, np.repeat(np.arange(n_cpu, dtype=np.uint32), mpg), k, eps)
+            out["sample_check"] = {"scored_equal": rs.emitted == e_cpu, "entries_equal": rs.num_entries == u_cpu,
+                                   "scored": e_cpu, "entries": u_cpu}
+            rs.free()
             out["cpu_baseline"] = {"value": e_cpu / tc, "unit": "phylo-k-mers/s", "cores": 1, "kind": "port",
                                    "sample": f"first {n_cpu} of {ng} branch groups of the same workload "
                                              f"({e_cpu} scored k-mers, {tc:.1f} s), oracle/ipk_oracle.c -O3, 1 thread "
