@@ -50,16 +50,85 @@ def exchange_parts(counts, entries, owner_offsets, dist, world):
     return recv_counts, recv_entries, source_offsets
 
 
-def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=1, rank=0):
+def _split_sizes(owner_offsets, world):
+    return [int(owner_offsets[o + 1] - owner_offsets[o]) for o in range(world)]
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _a2a(dist, out, inp, out_splits=None, in_splits=None, async_op=False):
+    """all_to_all_single; with the gloo rehearsal transport device tensors are staged through host memory."""
+    if inp.device.type == "cuda" and dist.get_backend() == "gloo":
+        o = out.cpu()
+        dist.all_to_all_single(o, inp.cpu().contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits)
+        out.copy_(o)
+        return _Done()
+    w = dist.all_to_all_single(out, inp.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                               async_op=async_op)
+    return w if async_op else _Done()
+
+
+def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=1, rank=0, overlap=True):
     """Scores this rank's groups and returns (this rank's database shard, parts) -- the state
-    `_phylo_kmer_db` has after explore_kmers (db_builder.cpp:576-627), sharded by k-mer owner."""
-    parts = engine.score_groups_keymajor(logp, mat_group, k, log_eps, n_owners=world)
+    `_phylo_kmer_db` has after explore_kmers (db_builder.cpp:576-627), sharded by k-mer owner.
+
+    With several ranks the groups are scored in two halves so that the all-to-all of the first half's
+    blocks (RCCL, its own stream) runs while the second half is being scored; the merge then takes
+    2 x world sources in the order (rank 0 first half, rank 0 second half, rank 1 first half, ...),
+    which is global group order."""
     if world == 1:
+        parts = engine.score_groups_keymajor(logp, mat_group, k, log_eps, n_owners=1)
         return engine.db_from_parts(parts, sigma, k), parts
-    counts, entries = parts.counts_tensor(), parts.entries_tensor()
-    rc, re_, so = exchange_parts(counts, entries, parts.owner_offsets, dist, world)
-    if world > 1:
-        import torch
+
+    import torch
+    mat_group = np.ascontiguousarray(mat_group, dtype=np.uint32)
+    order = list(dict.fromkeys(mat_group.tolist()))                      # groups in first-seen order
+    first = set(order[:len(order) // 2])
+    in_a = np.array([g in first for g in mat_group.tolist()])
+    na = int(in_a.sum())
+    two_halves = (overlap and len(order) >= 2 and hasattr(logp, "data_ptr")
+                  and bool(np.all(in_a[:na])) and not bool(np.any(in_a[na:])))      # halves must not interleave
+    if not two_halves:
+        parts = engine.score_groups_keymajor(logp, mat_group, k, log_eps, n_owners=world)
+        rc, re_, so = exchange_parts(parts.counts_tensor(), parts.entries_tensor(), parts.owner_offsets, dist, world)
         torch.cuda.current_stream().synchronize()
-    db = engine.merge_parts(sigma, k, rank, world, rc, re_, so)
-    return db, parts
+        return engine.merge_parts(sigma, k, rank, world, rc, re_, so), parts
+
+    dev = logp.device
+
+    def exchange(parts):
+        """Starts the transfer of one half's blocks; returns the receive buffers and the pending work."""
+        counts, entries = parts.counts_tensor(), parts.entries_tensor()
+        send = _split_sizes(parts.owner_offsets, world)
+        rs = torch.empty(world, dtype=torch.int64, device=dev)
+        _a2a(dist, rs, torch.tensor(send, dtype=torch.int64, device=dev))
+        recv = [int(x) for x in rs.tolist()]
+        rcounts = torch.empty_like(counts)
+        rentries = torch.empty((sum(recv), 2), dtype=torch.int32, device=dev)
+        works = [_a2a(dist, rcounts, counts, async_op=True),
+                 _a2a(dist, rentries, entries, recv, send, async_op=True)]
+        return dict(recv=recv, rcounts=rcounts, rentries=rentries, works=works, keep=(counts, entries))
+
+    pa = engine.score_groups_keymajor(logp[:na], mat_group[:na], k, log_eps, n_owners=world)
+    xa = exchange(pa)                                                    # in flight while the second half is scored
+    pb = engine.score_groups_keymajor(logp[na:], mat_group[na:], k, log_eps, n_owners=world)
+    xb = exchange(pb)
+    for w in xa["works"] + xb["works"]:
+        w.wait()
+    torch.cuda.current_stream().synchronize()
+    # sources in global group order: (rank r, first half), (rank r, second half)
+    counts = torch.stack([xa["rcounts"], xb["rcounts"]], dim=1).reshape(2 * world, -1).contiguous()
+    # both receive buffers are addressed from the lower of the two base pointers (entries are 8 bytes)
+    pa_ptr, pb_ptr = xa["rentries"].data_ptr(), xb["rentries"].data_ptr()
+    base = min(pa_ptr, pb_ptr) if xa["rentries"].numel() and xb["rentries"].numel() else (pa_ptr or pb_ptr)
+    offa = np.concatenate([[0], np.cumsum(xa["recv"])[:-1]]) + (pa_ptr - base) // 8 if xa["rentries"].numel() else np.zeros(world)
+    offb = np.concatenate([[0], np.cumsum(xb["recv"])[:-1]]) + (pb_ptr - base) // 8 if xb["rentries"].numel() else np.zeros(world)
+    so = np.stack([offa, offb], axis=1).reshape(-1).astype(np.uint64)
+    torch.cuda.synchronize()
+    db = engine.merge_parts(sigma, k, rank, world, counts, base, so)
+    pa.emitted += pb.emitted
+    pb.free()
+    return db, pa
