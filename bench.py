@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--groups", type=int, default=0, help="override the number of branch groups (0 = config's)")
     ap.add_argument("--alpha", type=float, default=0.0, help="override the column concentration")
     ap.add_argument("--output", default="db", choices=["db", "group"], help="db: key-major database shard; group: per-branch CSR")

@@ -37,5 +37,8 @@ def synth_matrices(n_mats, sites, sigma, alpha, seed, first_mat=0):
 CONFIGS = {
     "cfg2": dict(n_groups=1000, mats_per_group=2, sites=10000, sigma=4, k=10, omega=1.5, alpha=0.05, seed=42),
     "cfg3": dict(n_groups=1000, mats_per_group=2, sites=10000, sigma=4, k=12, omega=1.5, alpha=0.05, seed=42),
+    # D652-shaped stand-in for configs[4] (~650 taxa -> ~1300 branch groups, ~1.4 kb alignment); the real package needs
+    # git-LFS data + RAxML-ng + EPIK, none of which exist here
+    "cfg5": dict(n_groups=1300, mats_per_group=2, sites=1400, sigma=4, k=10, omega=1.5, alpha=0.05, seed=44),
     "cfg4": dict(n_groups=250, mats_per_group=2, sites=3000, sigma=20, k=6, omega=1.5, alpha=0.03, seed=43),
 }
