@@ -709,7 +709,9 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     uint64_t want = (uint64_t)((double)windows * ppw * 1.25 / CH) + slack;
     {
         const uint64_t have = std::min<uint64_t>(ctx->pool.cap / (CH * 8), ctx->desc.cap / 8);
-        if (have >= (uint64_t)((double)windows * ppw / CH) + slack) want = std::min<uint64_t>(want, have);
+        // expectation without the safety margins: pairs +10 %, ONE open chunk per (wave, bucket), the id batches
+        const uint64_t need = (uint64_t)((double)windows * ppw * 1.1 / CH) + (n_waves + ovf_waves) * (NBK * SUB + ALLOC_BATCH) + 1024;
+        if (have >= need) want = have;
     }
     for (int attempt = 0; attempt < 6; ++attempt) {
         uint64_t cap = std::min<uint64_t>(want, max_chunks);
@@ -748,7 +750,9 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         uint32_t n_ovf = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&n_ovf, p.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        const bool ovf_in_pool = n_ovf > 0 && gb < (1u << 22) && n_mats < (1u << 21) && pl.nwin < (1u << 21);
+        // a handful of big-list windows (< 0.2 % of the batch) are cheaper through the atomic kernel after pass 2 than
+        // through sort + pool kernel; flat posteriors put a large share of the pairs there and need the pool
+        const bool ovf_in_pool = (uint64_t)n_ovf * 500 >= windows && gb < (1u << 22) && n_mats < (1u << 21) && pl.nwin < (1u << 21);
         if (ovf_in_pool) {
             RC_TRY(ensure(ctx, ctx->tmp_a, (size_t)n_ovf * 8));
             RC_TRY(ensure(ctx, ctx->tmp_b, (size_t)n_ovf * 8));
