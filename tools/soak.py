@@ -1,0 +1,31 @@
+"""Soak: many calls of every output form with changing shapes in one process; watches device memory."""
+import sys, numpy as np, torch
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import ipk_amd
+from ipk_amd import distributed as D
+from ipk_amd.synth import synth_matrices
+rng = np.random.default_rng(1)
+eng = ipk_amd.Engine(0)
+base = None
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 150):
+    sigma = 4 if rng.random() < 0.7 else 20
+    k = int(rng.integers(4, 11)) if sigma == 4 else int(rng.integers(2, 5))
+    n_mats = int(rng.integers(1, 40)); sites = int(rng.integers(k, 400))
+    mats = synth_matrices(n_mats, sites, sigma, float(rng.choice([0.05, 0.3, 1.0])), int(rng.integers(1, 1 << 30)))
+    groups = rng.integers(0, max(1, n_mats // 2), size=n_mats).astype(np.uint32)
+    eps = ipk_amd.log_threshold(1.5, sigma, k)
+    mode = it % 3
+    if mode == 0:
+        r = eng.score_groups(mats, groups, k, eps); r.keys(); r.free()
+    elif mode == 1:
+        db, parts = D.build_db_shard(eng, mats, groups, k, eps, sigma)
+        db.filter_mif0(eng, 2 * n_mats + 1, ipk_amd.score_threshold(1.5, sigma, k)); db.filter_order()
+        db.free(); parts.free()
+    else:
+        r = eng.score_groups_positions(mats, groups, k, eps); r.positions(); r.free()
+    free = torch.cuda.mem_get_info()[0] / 1e9
+    if it == 20: base = free
+    if it % 25 == 0: print(f"iter {it}: free {free:.2f} GB", flush=True)
+print("free at 20:", base, "at end:", free)
+assert base - free < 2.0, "device memory keeps growing"
+print("soak ok")
