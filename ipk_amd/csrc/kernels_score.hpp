@@ -715,20 +715,21 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
         const uint2* s0 = pool + (size_t)e0.x * CH;
         const uint2* s1 = pool + (size_t)e1.x * CH;
         const uint32_t n0 = e0.y, n1 = (ci + NWV < c1) ? e1.y : 0u;
-        uint2 v[8];
+        constexpr int PER = CH / 64;                        // loads per lane and chunk
+        uint2 v[2 * PER];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = make_uint2(0, 0); v[4 + j] = make_uint2(0, 0);
+        for (int j = 0; j < PER; ++j) {
+            v[j] = make_uint2(0, 0); v[PER + j] = make_uint2(0, 0);
             if (lane + 64 * j < n0) v[j] = s0[lane + 64 * j];
-            if (lane + 64 * j < n1) v[4 + j] = s1[lane + 64 * j];
+            if (lane + 64 * j < n1) v[PER + j] = s1[lane + 64 * j];
         }
         ci += 2 * NWV;
         if (ci < c1) e0 = list[ci];
         if (ci + NWV < c1) e1 = list[ci + NWV];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PER; ++j) {
             if (lane + 64 * j < n0) atomicMax(&tab[v[j].x - k0], enc_score_bits(v[j].y));
-            if (lane + 64 * j < n1) atomicMax(&tab[v[4 + j].x - k0], enc_score_bits(v[4 + j].y));
+            if (lane + 64 * j < n1) atomicMax(&tab[v[PER + j].x - k0], enc_score_bits(v[PER + j].y));
         }
     }
     __syncthreads();
