@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import ipk_amd
 from ipk_amd.synth import synth_matrices, CONFIGS
 cfg = CONFIGS["cfg2"]
