@@ -446,6 +446,63 @@ template <int SIGMA, int K> uint32_t stream_nb() {
     if constexpr (TBL == 0) return 0; else return (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
 }
 
+// ---- exact-partition variant (count -> scan -> write -> reduce), kernels_score.hpp ---------------------
+constexpr int XP_NW = 8, XP_TW = 128;
+template <int SIGMA, int K> constexpr uint32_t xp_tbl()
+{
+    if (SIGMA == 20 && K == 6) return 32000u;                           // 2000 buckets per group
+    return stream_tbl<SIGMA, K>();
+}
+template <int SIGMA, int K> uint32_t xp_nb() {
+    constexpr uint32_t TBL = xp_tbl<SIGMA, K>();
+    if constexpr (TBL == 0) return 0; else return (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+}
+template <int SIGMA, int K> size_t xp_lds(bool write) {
+    constexpr uint32_t TBL = xp_tbl<SIGMA, K>();
+    if constexpr (TBL == 0) return 0;
+    else {
+        constexpr int CAP = fast_cap<SIGMA, K>();
+        constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+        return TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * (write ? 8 : 4);
+    }
+}
+template <int SIGMA, int K, bool WRITE>
+int launch_xp(ipkgpu_ctx* ctx, const XpParams& xp, uint32_t n_wg)
+{
+    constexpr uint32_t TBL = xp_tbl<SIGMA, K>();
+    if constexpr (TBL == 0) { (void)xp; (void)n_wg; return fail(ctx, IPKGPU_ERR_INVALID, "exact-partition variant unsupported for this sigma/k"); }
+    else {
+        constexpr int CAP = fast_cap<SIGMA, K>();
+        constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+        constexpr size_t lds = TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * (WRITE ? 8 : 4);
+        static_assert(lds <= 160 * 1024, "exact-partition LDS budget");
+        static_assert((TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8) % 8 == 0, "cursor alignment");
+        auto kern = score_xp_kernel<SIGMA, K, CAP, XP_TW, XP_NW, TBL, WRITE>;
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(XP_NW * 64), lds, ctx->stream, xp);
+        HIP_TRY(ctx, hipGetLastError());
+        return IPKGPU_OK;
+    }
+}
+template <int SIGMA, int K>
+int launch_xp_reduce(ipkgpu_ctx* ctx, uint32_t n_gb, uint32_t S, uint64_t T, const uint64_t* off, uint32_t* table)
+{
+    constexpr uint32_t TBL = xp_tbl<SIGMA, K>();
+    if constexpr (TBL == 0) { (void)n_gb; (void)S; (void)T; (void)off; (void)table; return fail(ctx, IPKGPU_ERR_INVALID, "exact-partition variant unsupported"); }
+    else {
+        constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+        constexpr int NT = TBL <= 16384 ? 512 : 1024;
+        constexpr size_t lds = (size_t)TBL * 4;
+        auto kern = reduce_ranges_kernel<TBL, NT>;
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(), off, S, NB, T, table);
+        HIP_TRY(ctx, hipGetLastError());
+        return IPKGPU_OK;
+    }
+}
+
 #define IPK_DISPATCH(SIGMA_V, K_V, EXPR_MACRO)                                         \
     do {                                                                               \
         if ((SIGMA_V) == 4) {                                                          \
@@ -524,6 +581,35 @@ int dispatch_overflow(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScorePa
 #define M_OV(S_, K_) return launch_overflow<S_, K_>(ctx, p)
     IPK_DISPATCH(sigma, k, M_OV);
 #undef M_OV
+    return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+}
+
+uint32_t xp_buckets(uint32_t sigma, uint32_t k)
+{
+#define M_XNB(S_, K_) return xp_nb<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_XNB);
+#undef M_XNB
+    return 0;
+}
+size_t xp_lds_bytes(uint32_t sigma, uint32_t k, bool write)
+{
+#define M_XLDS(S_, K_) return xp_lds<S_, K_>(write)
+    IPK_DISPATCH(sigma, k, M_XLDS);
+#undef M_XLDS
+    return 0;
+}
+int dispatch_xp(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const XpParams& xp, uint32_t n_wg, bool write)
+{
+#define M_XP(S_, K_) return write ? launch_xp<S_, K_, true>(ctx, xp, n_wg) : launch_xp<S_, K_, false>(ctx, xp, n_wg)
+    IPK_DISPATCH(sigma, k, M_XP);
+#undef M_XP
+    return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+}
+int dispatch_xp_reduce(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t n_gb, uint32_t S, uint64_t T, const uint64_t* off, uint32_t* table)
+{
+#define M_XR(S_, K_) return launch_xp_reduce<S_, K_>(ctx, n_gb, S, T, off, table)
+    IPK_DISPATCH(sigma, k, M_XR);
+#undef M_XR
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
 }
 
@@ -615,6 +701,66 @@ int run_prefix(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev)
 
 int scan_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out);
 
+// Exact-partition variant of one batch (kernels_score.hpp): count -> scan -> write -> reduce -> big-list windows.
+// ctx->gm holds the batch's group -> matrices CSR; p carries the shared counters and the big-list queue.
+int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t gb, uint32_t nb, const ScoreParams& p, uint32_t XNB)
+{
+    (void)nb;
+    const uint32_t tiles_per_mat = (pl.nwin + XP_TW - 1) / XP_TW;
+    const size_t lds_bytes = xp_lds_bytes(pl.sigma, pl.k, true);
+    const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / XP_NW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+    const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
+    // four rounds of resident workgroups balance the tail; a unit costs only its NB counters
+    const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((slots * 4) / gb, tiles_per_mat));
+    const uint64_t n_gb = (uint64_t)gb * XNB;
+    const uint64_t n_units = n_gb * S;
+    if (n_gb > 0x7fffffffull || (uint64_t)gb * S > 0x7fffffffull) return fail(ctx, IPKGPU_ERR_INVALID, "batch too large for one launch");
+    RC_TRY(ensure(ctx, ctx->gbcnt, n_units * 4));
+    RC_TRY(ensure(ctx, ctx->gboff, (n_units + 1) * 8));
+
+    XpParams xp;
+    StreamParams& sp = xp.s;
+    sp.logp = logp_dev; sp.best = ctx->best.as<float>();
+    sp.gm_off = ctx->gm.as<uint32_t>(); sp.gm_list = ctx->gm.as<uint32_t>() + gb + 1;
+    sp.sites = pl.sites; sp.nwin = pl.nwin; sp.tiles_per_mat = tiles_per_mat; sp.S = S;
+    sp.eps = pl.eps;
+    sp.pool = nullptr; sp.pool_cap = 0; sp.pool_next = nullptr; sp.desc = nullptr; sp.pool_ovf = nullptr;
+    sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot;
+    sp.flags = 0;
+    xp.cnt = ctx->gbcnt.as<uint32_t>();
+    xp.off = ctx->gboff.as<uint64_t>();
+
+    Stopwatch sw(ctx->stream);
+    const int ev_a = sw.mark();
+    RC_TRY(dispatch_xp(ctx, pl.sigma, pl.k, xp, gb * S, false));
+    RC_TRY(scan_u32(ctx, xp.cnt, n_units, ctx->gboff.as<uint64_t>()));
+    const int ev_b = sw.mark();
+    uint64_t total = 0;
+    uint32_t n_ovf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->gboff.as<uint64_t>() + n_units, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&n_ovf, p.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        if (total * 8 > ctx->pool.cap && total * 8 > free_b + ctx->pool.cap)
+            return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool (%llu pairs) does not fit device memory (lower workspace_bytes to score fewer groups per batch)",
+                        (unsigned long long)total);
+    }
+    RC_TRY(ensure(ctx, ctx->pool, std::max<uint64_t>(total, 1) * 8));
+    sp.pool = ctx->pool.as<uint2>();
+    const int ev_c = sw.mark();
+    RC_TRY(dispatch_xp(ctx, pl.sigma, pl.k, xp, gb * S, true));
+    const int ev_d = sw.mark();
+    RC_TRY(dispatch_xp_reduce(ctx, pl.sigma, pl.k, (uint32_t)n_gb, S, pl.table_size, ctx->gboff.as<uint64_t>(), ctx->table.as<uint32_t>()));
+    const int ev_e = sw.mark();
+    if (n_ovf > 0) RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));      // global atomics on the finished tables
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->acc_main_ms += sw.ms(ev_a, ev_b) + sw.ms(ev_c, ev_d);
+    ctx->acc_reduce_ms += sw.ms(ev_d, ev_e);
+    return IPKGPU_OK;
+}
+
 // Scores groups [g0, g0 + gb) into ctx->table ([gb][table_size]); *emitted_out = scored phylo-k-mers of the batch.
 int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t g0, uint32_t gb,
                      std::vector<uint32_t>& idx_host)
@@ -650,10 +796,14 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     p.flags = (uint32_t)(ctx->opt_variant == 99 ? 1 : 0);
     HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
     const uint32_t NBK = stream_buckets(pl.sigma, pl.k);
-    const bool use_stream = NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
+    const uint32_t XNB = xp_buckets(pl.sigma, pl.k);
+    // variant 0 = default: stream where its per-wave chunk state fits (all DNA k, AA k <= 5), exact partition for
+    // AA k=6; 1 = global atomics, 2 = stream (diagnostic flags honoured), 3 = exact partition wherever it exists
+    const bool use_xp = XNB != 0 && (ctx->opt_variant == 3 || (ctx->opt_variant == 0 && NBK == 0));
+    const bool use_stream = !use_xp && NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
     const uint32_t SNW = stream_waves(pl.sigma, pl.k), STW = stream_tile(pl.sigma, pl.k);
     const uint32_t s_tiles_per_mat = (pl.nwin + STW - 1) / STW;
-    if (!use_stream) {
+    if (!use_stream && !use_xp) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->table.p, 0, (size_t)gb * pl.table_size * 4, ctx->stream));
         Stopwatch sw(ctx->stream);
         const int a = sw.mark();
@@ -678,6 +828,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     RC_TRY(ensure(ctx, ctx->gm, gm.size() * 4));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->gm.p, gm.data(), gm.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (use_xp) return score_batch_xp(ctx, pl, logp_dev, gb, nb, p, XNB);
 
     // Segments (workgroups) per group.  More workgroups balance the tail of the persistent kernel, but every
     // wavefront keeps one open chunk per key bucket, so workgroups x waves x buckets must stay well below

@@ -1,5 +1,6 @@
 // kernels_score.hpp -- prefix array + scoring kernels (see ipkgpu.hip for the data layout).
 #pragma once
+#include <type_traits>
 #include "dcla_device.hpp"
 
 namespace ipkgpu {
@@ -738,6 +739,199 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
         for (uint32_t i = threadIdx.x; i < nslots / 4; i += NT) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<uint4*>(tab)[i];
     } else {
         for (uint32_t i = threadIdx.x; i < nslots; i += NT) dst[i] = tab[i];
+    }
+}
+
+
+// =================================================================================================
+// Exact-partition variant ("xp"): for key spaces with thousands of buckets per group (AA k=6: 2000) the
+// per-wave open chunks of the stream variant do not fit LDS.  Scoring a window is cheap next to a global
+// atomic per scored phylo-k-mer, so the windows are scored TWICE:
+//   count  score_xp_kernel<.., false>: pairs per (group, bucket, segment) in workgroup-shared LDS counters
+//   scan   exclusive offsets, laid out (group, bucket, segment) so a (group, bucket) range is contiguous
+//   write  score_xp_kernel<.., true>: the same windows again; pairs go to their exact pool positions
+//   reduce reduce_ranges_kernel: one workgroup per (group, bucket), LDS max-reduce, dense table slice
+// The final cross product runs one L entry ("row") at a time: a row's pairs share the high code digits
+// a.x * mulR, hence (TBL a multiple of mulR) one bucket, and land in one contiguous run of the pool.
+// Counting is done with one row per LANE (the row's survivor count ends in that lane, 64 bucket
+// reservations per LDS atomic instruction); writing walks the rows with the lanes over R.
+// Same sets, same float operations as for_each_pair/join (pk_compute.cpp:90-91).
+// =================================================================================================
+struct XpParams {
+    StreamParams s;                // pool_next / desc / pool_ovf unused
+    uint32_t* cnt;                 // [(group * NB + bucket) * S + segment]   (count pass output)
+    const uint64_t* off;           // exclusive scan of cnt                   (write pass input)
+};
+
+template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL, bool WRITE>
+__global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const StreamParams& p = xp.s;
+    using TG = TileGeo<SIGMA, K, TW>;
+    constexpr uint32_t T = ipow(SIGMA, K);
+    constexpr uint32_t NB = (T + TBL - 1) / TBL;
+    constexpr uint32_t WS = stream_wave_scratch<SIGMA, K, CAP>();
+    constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
+    static_assert(TBL % mulR == 0, "a row of the final join must stay inside one bucket");
+    constexpr uint32_t RPB = TBL / mulR;                    // rows (L codes) per bucket
+    using Cursor = typename std::conditional<WRITE, unsigned long long, uint32_t>::type;
+    float* cols = reinterpret_cast<float*>(smem);
+    float* best = cols + TG::COLS_F;
+    uint2* scratch_all = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
+    Cursor* cur = reinterpret_cast<Cursor*>(scratch_all + (size_t)NW * WS);     // workgroup-shared, one per bucket
+
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x / p.S, seg = blockIdx.x - g * p.S;
+    const uint32_t m0 = p.gm_off[g], nm = p.gm_off[g + 1] - m0;
+    const uint32_t total_tiles = nm * p.tiles_per_mat;
+    const uint32_t t_lo = (uint32_t)(((uint64_t)total_tiles * seg) / p.S);
+    const uint32_t t_hi = (uint32_t)(((uint64_t)total_tiles * (seg + 1)) / p.S);
+    const size_t ub = (size_t)g * NB * p.S + seg;           // this unit's slot of bucket b: ub + b * S
+    for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) {
+        if constexpr (WRITE) cur[b] = xp.off[ub + (size_t)b * p.S];
+        else cur[b] = 0;
+    }                                                       // (the first tile's barriers order this before any use)
+
+    uint2* scratch = scratch_all + (size_t)wave * WS;
+    unsigned long long emitted = 0;                         // per lane
+
+    for (uint32_t t = t_lo; t < t_hi; ++t) {
+        const uint32_t q = t / p.tiles_per_mat, tile = t - q * p.tiles_per_mat;
+        const uint32_t mat = p.gm_list[m0 + q];
+        const uint32_t t0 = tile * TW;
+        const uint32_t nw = min((uint32_t)TW, p.nwin - t0);
+        const uint32_t ncol = nw + K - 1;
+        __syncthreads();                                   // previous tile fully consumed
+        {
+            const float4* src = reinterpret_cast<const float4*>(p.logp + ((size_t)mat * p.sites + t0) * SIGMA);
+            float4* dst = reinterpret_cast<float4*>(cols);
+            const uint32_t n4 = ncol * (SIGMA / 4);
+            for (uint32_t i = threadIdx.x; i < n4; i += NW * 64) dst[i] = src[i];
+            const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + t0;
+            for (uint32_t i = threadIdx.x; i <= ncol; i += NW * 64) best[i] = bsrc[i];
+        }
+        __syncthreads();
+        for (uint32_t w = wave; w < nw; w += NW) {
+            WinCtx c{cols, best, w};
+            const uint2 *L, *R;
+            uint32_t nL, nR;
+            bool ok;
+            if constexpr (HalvesDD<SIGMA, K>::OK) ok = build_halves_dd<SIGMA, K, CAP>(c, p.eps, scratch, L, nL, R, nR);
+            else ok = build_halves<SIGMA, K, CAP>(c, p.eps, scratch, L, nL, R, nR);
+            if (!ok) {                                     // big-list window: queued once, by the count pass
+                if (!WRITE && lane == 0) {
+                    const uint32_t qi = atomicAdd(p.ovf_count, 1u);
+                    p.ovf_queue[qi] = ((unsigned long long)mat << 32) | (unsigned long long)(t0 + w);
+                }
+                continue;
+            }
+            if (nL == 0 || nR == 0) continue;
+            // write pass: R lives in registers (lane l holds R[l], R[l + 64], ...), padded with -inf scores that
+            // fail every strict comparison, so the row loop below touches no LDS
+            constexpr int RC = (Geo<SIGMA, K - K / 2, CAP>::CAPH + 63) / 64;
+            uint32_t rx[RC];
+            float ry[RC];
+            if constexpr (WRITE) {
+#pragma unroll
+                for (int ch = 0; ch < RC; ++ch) {
+                    const uint32_t j = (uint32_t)ch * 64 + lane;
+                    rx[ch] = 0; ry[ch] = -__builtin_inff();
+                    if (j < nR) { const uint2 b = R[j]; rx[ch] = b.x; ry[ch] = __uint_as_float(b.y); }
+                }
+            }
+            for (uint32_t ib = 0; ib < nL; ib += 64) {
+                // one row per lane: how many of its pairs pass
+                const bool vr = ib + lane < nL;
+                uint2 a = make_uint2(0, 0);
+                if (vr) a = L[ib + lane];
+                const float ay = __uint_as_float(a.y);
+                uint32_t cnt = 0;
+#pragma unroll 4
+                for (uint32_t j = 0; j < nR; ++j) {
+                    const float s = ay + __uint_as_float(R[j].y);              // pk_compute.cpp:90
+                    cnt += (s > p.eps) ? 1u : 0u;                              // :91
+                }
+                if (!vr) cnt = 0;
+                const uint32_t bk = a.x / RPB;
+                if constexpr (!WRITE) {
+                    emitted += cnt;
+                    if (cnt) atomicAdd(&cur[bk], cnt);
+                } else {
+                    unsigned long long pos = 0;
+                    if (cnt) pos = atomicAdd(&cur[bk], (unsigned long long)cnt);
+                    const uint32_t rows = min(64u, nL - ib);
+                    for (uint32_t r = 0; r < rows; ++r) {
+                        const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)r);
+                        if (cr == 0) continue;
+                        const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos, (int)r);
+                        const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos >> 32), (int)r);
+                        uint2* dst = p.pool + (((unsigned long long)phi << 32) | plo);
+                        const uint32_t ax = (uint32_t)__builtin_amdgcn_readlane((int)a.x, (int)r) * mulR;
+                        const float ayr = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)a.y, (int)r));
+                        uint32_t done = 0;
+#pragma unroll
+                        for (int ch = 0; ch < RC; ++ch) {
+                            if ((uint32_t)ch * 64 >= nR) break;
+                            const float s = ayr + ry[ch];                       // the count pass' operation, same operands
+                            const bool pass = s > p.eps;
+                            const uint64_t m = __ballot(pass);
+                            if (pass) dst[done + mbcnt(m)] = make_uint2(ax + rx[ch], __float_as_uint(s));
+                            done += (uint32_t)__popcll(m);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (!WRITE) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) xp.cnt[ub + (size_t)b * p.S] = cur[b];
+        // wave sum of the per-lane counts
+        for (int o = 32; o > 0; o >>= 1) emitted += __shfl_down(emitted, o, 64);
+        if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);
+    }
+}
+
+// xp pass 3: one workgroup per (group, bucket); its pairs are ONE contiguous range of the pool
+// (segments of a (group, bucket) are adjacent in the scan order).
+template <uint32_t TBL, int NT>
+__global__ __launch_bounds__(NT) void reduce_ranges_kernel(const uint2* __restrict__ pool, const uint64_t* __restrict__ off,
+                                                          uint32_t S, uint32_t NB, uint64_t T, uint32_t* __restrict__ table)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t gb = blockIdx.x;
+    const uint32_t g = gb / NB, b = gb - g * NB;
+    const uint64_t key0 = (uint64_t)b * TBL;
+    const uint32_t nslots = (uint32_t)min((uint64_t)TBL, T - key0);
+    const uint64_t r0 = off[(size_t)gb * S], r1 = off[(size_t)gb * S + S];
+    constexpr int PER = 4;
+    uint2 v[PER];
+    uint64_t i = r0 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (i + (uint64_t)j * NT < r1) v[j] = pool[i + (uint64_t)j * NT];   // in flight while the table is cleared
+    for (uint32_t z = threadIdx.x; z < TBL / 4; z += NT) reinterpret_cast<uint4*>(tab)[z] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t k0 = (uint32_t)key0;
+    while (i < r1) {
+        uint2 cur[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) cur[j] = v[j];
+        const uint64_t ci = i;
+        i += (uint64_t)PER * NT;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) if (i + (uint64_t)j * NT < r1) v[j] = pool[i + (uint64_t)j * NT];
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (ci + (uint64_t)j * NT < r1) atomicMax(&tab[cur[j].x - k0], enc_score_bits(cur[j].y));
+    }
+    __syncthreads();
+    uint32_t* dst = table + (size_t)g * T + key0;
+    if ((nslots & 3u) == 0 && ((((size_t)g * T + key0) & 3u) == 0)) {
+        for (uint32_t z = threadIdx.x; z < nslots / 4; z += NT) reinterpret_cast<uint4*>(dst)[z] = reinterpret_cast<uint4*>(tab)[z];
+    } else {
+        for (uint32_t z = threadIdx.x; z < nslots; z += NT) dst[z] = tab[z];
     }
 }
 

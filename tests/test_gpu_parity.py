@@ -193,6 +193,32 @@ def test_v1_variant_still_matches(engine):
         engine.set_option("variant", 0)
 
 
+@pytest.mark.parametrize("sigma,k,sites,alpha", [(4, 5, 60, 0.3), (4, 8, 120, 0.2), (4, 10, 300, 0.1), (4, 10, 200, 1.0), (4, 12, 80, 0.1),
+                                                 (20, 2, 40, 0.2), (20, 4, 40, 0.05), (20, 5, 30, 0.03), (20, 6, 40, 0.03)])
+def test_exact_partition_variant(engine, sigma, k, sites, alpha):
+    """variant=3: count -> scan -> write -> LDS reduce (the default for AA k=6) on every (sigma, k) it exists for."""
+    mats = synth_matrices(5, sites, sigma, alpha, 300 + 10 * sigma + k)
+    groups = np.array([3, 8, 3, 8, 1], dtype=np.uint32)
+    engine.set_option("variant", 3)
+    try:
+        check_against_oracle(engine, mats, groups, k, co.log_threshold(1.5, sigma, k))
+    finally:
+        engine.set_option("variant", 0)
+
+
+def test_exact_partition_is_the_aa_k6_default_and_handles_big_lists(engine):
+    """AA k=6 takes the exact-partition path by default; broader columns push half lists past the fast path's
+    capacity, so the big-list windows (queued by the count pass only) are exercised too."""
+    mats = synth_matrices(3, 40, 20, 0.06, 77)          # 43 of the 105 windows have a half list above 512 entries
+    eps = co.log_threshold(1.5, 20, 6)
+    check_against_oracle(engine, mats, [5, 5, 6], 6, eps)
+    engine.set_option("variant", 1)
+    try:
+        check_against_oracle(engine, mats, [5, 5, 6], 6, eps)
+    finally:
+        engine.set_option("variant", 0)
+
+
 @pytest.mark.parametrize("sigma,k,sites", [(4, 8, 90), (4, 10, 150), (20, 3, 30), (20, 6, 14)])
 def test_keep_positions_variant(engine, sigma, k, sites):
     """Row a11 (ipk-aa-pos): kept score + position of the FIRST window reaching it."""
