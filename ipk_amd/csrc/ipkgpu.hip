@@ -62,6 +62,9 @@ struct ipkgpu_ctx {
     int64_t opt_pool_chunks = 0;      // test knob: size of the FIRST pair-pool attempt (forces the grow-and-redo path)
     DevBuf table, best, ovfq, counts, offsets, goff, idx, branch, scan_sums, scan_boff, tmp_a, tmp_b, tmp_c;
     DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
+    DevBuf mask;                 // occupancy bits of ctx->table ([groups in batch][mask_words]) when mask_valid
+    bool mask_valid = false;
+    uint64_t mask_words = 0;
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
     double acc_main_ms = 0, acc_reduce_ms = 0;   // dominant scoring kernel / LDS reduce pass of the current call
     // caching allocator for result buffers: hipMalloc/hipFree of multi-GB blocks costs 10-100 ms, so
@@ -272,7 +275,7 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
                       &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
-                      &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm};
+                      &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->mask};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
     if (ctx->small) (void)hipFree(ctx->small);
@@ -425,7 +428,7 @@ int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* ta
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(),
-                           ctx->gboff.as<uint64_t>(), ctx->clist.as<uint2>(), NB, T, table);
+                           ctx->gboff.as<uint64_t>(), ctx->clist.as<uint2>(), NB, T, table, ctx->mask.as<uint32_t>(), ctx->mask_words);
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
     }
@@ -497,7 +500,8 @@ int launch_xp_reduce(ipkgpu_ctx* ctx, uint32_t n_gb, uint32_t S, uint64_t T, con
         auto kern = reduce_ranges_kernel<TBL, NT>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(), off, S, NB, T, table);
+        hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(), off, S, NB, T, table,
+                           ctx->mask.as<uint32_t>(), ctx->mask_words);
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
     }
@@ -703,7 +707,7 @@ int scan_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out);
 
 // Exact-partition variant of one batch (kernels_score.hpp): count -> scan -> write -> reduce -> big-list windows.
 // ctx->gm holds the batch's group -> matrices CSR; p carries the shared counters and the big-list queue.
-int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t gb, uint32_t nb, const ScoreParams& p, uint32_t XNB)
+int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t gb, uint32_t nb, ScoreParams& p, uint32_t XNB)
 {
     (void)nb;
     const uint32_t tiles_per_mat = (pl.nwin + XP_TW - 1) / XP_TW;
@@ -756,6 +760,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     const int ev_e = sw.mark();
     if (n_ovf > 0) RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));      // global atomics on the finished tables
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->mask_valid = true;
     ctx->acc_main_ms += sw.ms(ev_a, ev_b) + sw.ms(ev_c, ev_d);
     ctx->acc_reduce_ms += sw.ms(ev_d, ev_e);
     return IPKGPU_OK;
@@ -794,6 +799,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     p.ovf_queue = ctx->ovfq.as<unsigned long long>();
     p.ovf_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 16);
     p.flags = (uint32_t)(ctx->opt_variant == 99 ? 1 : 0);
+    p.mask = nullptr; p.mask_words = 0;
+    ctx->mask_valid = false;
     HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
     const uint32_t NBK = stream_buckets(pl.sigma, pl.k);
     const uint32_t XNB = xp_buckets(pl.sigma, pl.k);
@@ -828,6 +835,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     RC_TRY(ensure(ctx, ctx->gm, gm.size() * 4));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->gm.p, gm.data(), gm.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // occupancy bits of the tables: written by the LDS reduce pass, kept current by the big-list kernel, read by km_count
+    ctx->mask_words = (pl.table_size + 31) / 32;
+    RC_TRY(ensure(ctx, ctx->mask, (size_t)gb * ctx->mask_words * 4));
+    p.mask = ctx->mask.as<uint32_t>(); p.mask_words = ctx->mask_words;
     if (use_xp) return score_batch_xp(ctx, pl, logp_dev, gb, nb, p, XNB);
 
     // Segments (workgroups) per group.  More workgroups balance the tail of the persistent kernel, but every
@@ -953,6 +964,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         const int ev_d = sw.mark();
         if (n_ovf > 0 && !ovf_in_pool) RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->mask_valid = true;
         ctx->acc_main_ms += sw.ms(ev_a, ev_b);
         ctx->acc_reduce_ms += sw.ms(ev_c, ev_d);
         return IPKGPU_OK;
@@ -1166,6 +1178,7 @@ int ipkgpu_score_groups_positions(ipkgpu_ctx* ctx, const float* logp, uint32_t n
         p.mat_list = ctx->idx.as<uint32_t>(); p.mat_slot = ctx->idx.as<uint32_t>() + n_mats;
         p.n_batch_mats = nb; p.sites = sites; p.nwin = pl.nwin; p.tiles_per_mat = pl.tiles_per_mat; p.eps = log_eps;
         p.table = ctx->table.p; p.table_size = pl.table_size; p.mat_rank = ctx->branch.as<uint32_t>();
+        p.mask = nullptr; p.mask_words = 0;
         p.emitted = reinterpret_cast<unsigned long long*>(ctx->small);
         p.ovf_queue = ctx->ovfq.as<unsigned long long>();
         p.ovf_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 16);
@@ -1413,8 +1426,12 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         Batch& b = batches.back();
         HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.counts, n_slots_all * 4));
         HIP_TRY(ctx, hipMemsetAsync(b.counts, 0, n_slots_all * 4, ctx->stream));
-        hipLaunchKernelGGL(km_count_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ctx->table.as<uint32_t>(), T, gb, P, slots, b.counts);
+        if (ctx->mask_valid)
+            hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->mask.as<uint32_t>(), ctx->mask_words, T, gb, P, slots, b.counts);
+        else
+            hipLaunchKernelGGL(km_count_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->table.as<uint32_t>(), T, gb, P, slots, b.counts);
         HIP_TRY(ctx, hipGetLastError());
         RC_TRY(ensure(ctx, ctx->offsets, (n_slots_all + 1) * 8));
         RC_TRY(scan_u32(ctx, b.counts, n_slots_all, ctx->offsets.as<uint64_t>()));

@@ -35,6 +35,26 @@ __global__ __launch_bounds__(256) void km_count_kernel(const uint32_t* __restric
     counts[o * slots + q] = c;               // padded slots (q * P + o >= T) stay at their memset 0
 }
 
+// The same counts from the occupancy bits the LDS reduce passes leave behind (kernels_score.hpp,
+// store_slice_mask): 1/32 of the bytes of the dense tables.
+__global__ __launch_bounds__(256) void km_count_mask_kernel(const uint32_t* __restrict__ mask, uint64_t W, uint64_t T,
+                                                            uint32_t G, uint32_t P, uint64_t slots, uint32_t* __restrict__ counts)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= T) return;
+    const uint32_t* m = mask + (x >> 5);
+    const uint32_t sh = (uint32_t)x & 31u;
+    uint32_t c = 0, g = 0;
+    for (; g + 4 <= G; g += 4) {
+        const uint32_t v0 = m[(size_t)(g + 0) * W], v1 = m[(size_t)(g + 1) * W];
+        const uint32_t v2 = m[(size_t)(g + 2) * W], v3 = m[(size_t)(g + 3) * W];
+        c += ((v0 >> sh) & 1u) + ((v1 >> sh) & 1u) + ((v2 >> sh) & 1u) + ((v3 >> sh) & 1u);
+    }
+    for (; g < G; ++g) c += (m[(size_t)g * W] >> sh) & 1u;
+    const uint64_t o = x % P, q = x / P;
+    counts[o * slots + q] = c;
+}
+
 // ---- generic exclusive scan of u32 -> u64 (three kernels) -------------------------------------
 constexpr uint32_t SCAN_BLOCK = 4096;
 

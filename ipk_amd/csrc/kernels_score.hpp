@@ -70,6 +70,8 @@ struct ScoreParams {
     unsigned long long* ovf_queue; // (mat << 32 | window start) of windows whose lists overflowed
     uint32_t* ovf_count;
     uint32_t flags;               // bit 0 (diagnostic builds of bench only): skip the table update
+    uint32_t* mask;               // [slots][mask_words] occupancy bits of the tables (bit x % 32 of word x / 32), or null:
+    uint64_t mask_words;          //   written by the LDS reduce passes, kept current by the big-list kernel
 };
 
 // ipk::put (branch_group.cpp:88-101): keep the larger score; the first one wins ties.
@@ -243,8 +245,13 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
                 const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
                 const bool pass = valid && (s > p.eps);                            // :91
                 if (pass && !(p.flags & 1u)) {
-                    if constexpr (POS) PutScorePos{tab64, inv_seq}(a.x * mulR + b.x, __float_as_uint(s));
-                    else PutScore{tab}(a.x * mulR + b.x, __float_as_uint(s));
+                    const uint32_t idx = a.x * mulR + b.x;
+                    if constexpr (POS) PutScorePos{tab64, inv_seq}(idx, __float_as_uint(s));
+                    else {
+                        const uint32_t old = atomicMax(tab + idx, enc_score_bits(__float_as_uint(s)));   // PutScore
+                        if (old == 0u && p.mask)                                                      // first score of this slot
+                            atomicOr(p.mask + (size_t)p.mat_slot[mat] * p.mask_words + (idx >> 5), 1u << (idx & 31u));
+                    }
                 }
                 cnt += (uint32_t)__popcll(__ballot(pass));
             }
@@ -687,13 +694,29 @@ __global__ __launch_bounds__(256) void chunk_scatter_kernel(const unsigned long 
     list[off[gb] + atomicAdd(&cur[gb], 1u)] = make_uint2(i, (uint32_t)d);      // (chunk id, pair count)
 }
 
+// Occupancy bits of a finished LDS table slice (slots key0 .. key0 + nslots of one group; key0 a multiple of 32):
+// bit x % 32 of word x / 32 says table[x] != 0.  km_count sums these bits instead of re-reading the dense tables.
+__device__ __forceinline__ void store_slice_mask(const uint32_t* tab, uint32_t nslots, uint32_t* mask_words, uint32_t nthreads)
+{
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, nwv = nthreads >> 6;
+    for (uint32_t c = wave * 64; c < nslots; c += nwv * 64) {
+        const uint32_t v = (c + lane < nslots) ? tab[c + lane] : 0u;
+        const uint64_t m = __ballot(v != 0u);
+        if (lane == 0) {
+            mask_words[c >> 5] = (uint32_t)m;
+            if (c + 32 < nslots) mask_words[(c >> 5) + 1] = (uint32_t)(m >> 32);
+        }
+    }
+}
+
 // pass 2: one workgroup per (group, bucket): LDS max-reduce of the bucket's chunks, then the table slice.
 // Each wave takes two chunks per trip and issues all of their pair loads (8 x 512 B) before the first
 // LDS atomic, so ~4 KiB per wave are in flight.
 template <uint32_t TBL, int NT>
 __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restrict__ pool,
                                                            const uint64_t* __restrict__ off, const uint2* __restrict__ list,
-                                                           uint32_t NB, uint64_t T, uint32_t* __restrict__ table)
+                                                           uint32_t NB, uint64_t T, uint32_t* __restrict__ table,
+                                                           uint32_t* __restrict__ mask, uint64_t mask_words)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
@@ -740,6 +763,7 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
     } else {
         for (uint32_t i = threadIdx.x; i < nslots; i += NT) dst[i] = tab[i];
     }
+    if (mask) store_slice_mask(tab, nslots, mask + (size_t)g * mask_words + (key0 >> 5), NT);
 }
 
 
@@ -897,7 +921,8 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
 // (segments of a (group, bucket) are adjacent in the scan order).
 template <uint32_t TBL, int NT>
 __global__ __launch_bounds__(NT) void reduce_ranges_kernel(const uint2* __restrict__ pool, const uint64_t* __restrict__ off,
-                                                          uint32_t S, uint32_t NB, uint64_t T, uint32_t* __restrict__ table)
+                                                          uint32_t S, uint32_t NB, uint64_t T, uint32_t* __restrict__ table,
+                                                          uint32_t* __restrict__ mask, uint64_t mask_words)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
@@ -933,6 +958,7 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(const uint2* __restri
     } else {
         for (uint32_t z = threadIdx.x; z < nslots; z += NT) dst[z] = tab[z];
     }
+    if (mask) store_slice_mask(tab, nslots, mask + (size_t)g * mask_words + (key0 >> 5), NT);
 }
 
 }  // namespace ipkgpu

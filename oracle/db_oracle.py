@@ -33,9 +33,11 @@ def build_db(group_results):
 
 def db_shard_arrays(db, sigma, k, owner, world):
     """Owner's shard as (keys asc, key_offsets, branches, score_bits)."""
-    keys = sorted(x for x in db if int(dense_code([x], sigma, k)[0]) % world == owner)
-    if sigma != 4:   # ascending dense code == ascending packed code (both are lexicographic in the symbols)
-        keys = sorted(keys, key=lambda x: int(dense_code([x], sigma, k)[0]))
+    allk = np.fromiter(db.keys(), dtype=np.uint64, count=len(db))
+    dense = dense_code(allk, sigma, k)
+    mine = (dense % np.uint64(world)) == np.uint64(owner)
+    # ascending dense code == ascending packed code (both are lexicographic in the symbols)
+    keys = allk[mine][np.argsort(dense[mine], kind="stable")].tolist()
     off, br, sc = [0], [], []
     for x in keys:
         for b, s in db[x]:

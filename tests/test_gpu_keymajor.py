@@ -43,6 +43,26 @@ def test_single_owner_db(engine, sigma, k, sites, alpha):
     db.free(); parts.free()
 
 
+@pytest.mark.parametrize("sigma,k,sites,alpha,variant", [(20, 6, 40, 0.06, 0), (4, 12, 1500, 0.05, 0), (4, 10, 120, 0.1, 1),
+                                                          (4, 10, 120, 0.1, 3), (20, 2, 50, 0.2, 0)])
+def test_db_counts_follow_every_scoring_variant(engine, sigma, k, sites, alpha, variant):
+    """The key-major counts come from the occupancy bits the LDS reduce leaves behind (stream / exact-partition
+    variants) -- kept current by the big-list kernel's atomics, which the first two cases exercise (42 of 105 and 4 of
+    4467 windows have a half list above the fast path's 512 entries) -- and from the dense tables otherwise."""
+    mats = synth_matrices(3, sites, sigma, alpha, 640 + k)
+    groups = np.array([12, 12, 4], dtype=np.uint32)
+    eps = co.log_threshold(1.5, sigma, k)
+    full, emitted = oracle_db(mats, groups, k, eps)
+    engine.set_option("variant", variant)
+    try:
+        db, parts = D.build_db_shard(engine, mats, groups, k, eps, sigma)
+    finally:
+        engine.set_option("variant", 0)
+    assert parts.emitted == emitted
+    check_shard(db, full, sigma, k, 0, 1)
+    db.free(); parts.free()
+
+
 @pytest.mark.parametrize("world,sigma,k", [(2, 4, 8), (3, 4, 7), (8, 4, 6), (3, 20, 3)])
 def test_simulated_ranks_exchange(engine, world, sigma, k):
     """P ranks emulated on one GPU: each 'rank' scores its shard of groups with n_owners = P; owner o
