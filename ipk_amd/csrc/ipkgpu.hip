@@ -450,7 +450,7 @@ template <int SIGMA, int K> uint32_t stream_nb() {
 }
 
 // ---- exact-partition variant (count -> scan -> write -> reduce), kernels_score.hpp ---------------------
-constexpr int XP_NW = 8, XP_TW = 128;
+constexpr int XP_NW = 10, XP_TW = 128;
 template <int SIGMA, int K> constexpr uint32_t xp_tbl()
 {
     if (SIGMA == 20 && K == 6) return 32000u;                           // 2000 buckets per group

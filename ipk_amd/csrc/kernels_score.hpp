@@ -248,8 +248,10 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
                     const uint32_t idx = a.x * mulR + b.x;
                     if constexpr (POS) PutScorePos{tab64, inv_seq}(idx, __float_as_uint(s));
                     else {
+                        // the returned old value says whether this is the slot's first score (measured cheaper than a plain
+                        // read of the mask word followed by a conditional atomicOr: 0.62 vs 0.74 ms at cfg2)
                         const uint32_t old = atomicMax(tab + idx, enc_score_bits(__float_as_uint(s)));   // PutScore
-                        if (old == 0u && p.mask)                                                      // first score of this slot
+                        if (old == 0u && p.mask)
                             atomicOr(p.mask + (size_t)p.mat_slot[mat] * p.mask_words + (idx >> 5), 1u << (idx & 31u));
                     }
                 }
@@ -777,10 +779,31 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
 //   reduce reduce_ranges_kernel: one workgroup per (group, bucket), LDS max-reduce, dense table slice
 // The final cross product runs one L entry ("row") at a time: a row's pairs share the high code digits
 // a.x * mulR, hence (TBL a multiple of mulR) one bucket, and land in one contiguous run of the pool.
-// Counting is done with one row per LANE (the row's survivor count ends in that lane, 64 bucket
-// reservations per LDS atomic instruction); writing walks the rows with the lanes over R.
-// Same sets, same float operations as for_each_pair/join (pk_compute.cpp:90-91).
+// Counting runs with one row per LANE (64 bucket reservations per LDS atomic instruction).  The write
+// pass sorts R by score first, so a row's passing pairs are a prefix of it (length by binary search,
+// equal to the count pass' number) and leave as one dense run, the lanes over the prefix.  Same sets, same float operation per pair as for_each_pair/join
+// (pk_compute.cpp:90-91).
 // =================================================================================================
+// rank[c] += #{i < n : key(R[i]) > kj[c]} for the lane's NCH keys; key = (score code << 32) | ~position.
+// Four LDS reads in flight per trip; NCH is a compile-time count so the body is branch-free.
+template <int NCH, int RC>
+__device__ __forceinline__ void xp_rank_by_counting(const uint2* R, uint32_t n, const unsigned long long (&kj)[RC], uint32_t (&rank)[RC])
+{
+    for (uint32_t i = 0; i < n; i += 4) {
+        uint32_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = R[min(i + (uint32_t)u, n - 1)].y;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // entries past the end repeat the last one with a position that loses every comparison it should not win
+            const bool live = i + (uint32_t)u < n;
+            const unsigned long long ki = live ? (((unsigned long long)enc_score_bits(e[u]) << 32) | (unsigned long long)(0xFFFFFFFFu - (i + (uint32_t)u))) : 0ull;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) rank[c] += (ki > kj[c]) ? 1u : 0u;
+        }
+    }
+}
+
 struct XpParams {
     StreamParams s;                // pool_next / desc / pool_ovf unused
     uint32_t* cnt;                 // [(group * NB + bucket) * S + segment]   (count pass output)
@@ -851,30 +874,73 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
                 continue;
             }
             if (nL == 0 || nR == 0) continue;
-            // write pass: R lives in registers (lane l holds R[l], R[l + 64], ...), padded with -inf scores that
-            // fail every strict comparison, so the row loop below touches no LDS
+            nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)nL);            // wave-uniform by construction: keep them scalar
+            nR = (uint32_t)__builtin_amdgcn_readfirstlane((int)nR);
+            // R sorted by score, descending (rank by counting, in place; ties by position).  fl(a + b) is monotone
+            // in b, so the pairs of a row that pass `a.score + b.score > eps` (pk_compute.cpp:90-91) are exactly a
+            // PREFIX of the sorted R -- the reference's own loop shape (sort at :61-70, break at the first failure,
+            // :73-110): a row's count is a binary search, and its pairs leave as one dense run.
+            // The count pass needs only the prefix LENGTHS, which do not depend on the order of R: it counts the
+            // passing pairs of a row over the unsorted list and skips the sort.
             constexpr int RC = (Geo<SIGMA, K - K / 2, CAP>::CAPH + 63) / 64;
+            uint2* Rs = const_cast<uint2*>(R);
             uint32_t rx[RC];
             float ry[RC];
             if constexpr (WRITE) {
+                unsigned long long kj[RC];
+                uint32_t rank[RC], ryb[RC];
 #pragma unroll
                 for (int ch = 0; ch < RC; ++ch) {
                     const uint32_t j = (uint32_t)ch * 64 + lane;
-                    rx[ch] = 0; ry[ch] = -__builtin_inff();
-                    if (j < nR) { const uint2 b = R[j]; rx[ch] = b.x; ry[ch] = __uint_as_float(b.y); }
+                    rx[ch] = 0; ryb[ch] = 0; kj[ch] = 0; rank[ch] = 0;
+                    if (j < nR) {
+                        const uint2 b = R[j];
+                        rx[ch] = b.x; ryb[ch] = b.y;
+                        kj[ch] = ((unsigned long long)enc_score_bits(b.y) << 32) | (unsigned long long)(0xFFFFFFFFu - j);
+                    }
+                }
+                switch ((nR + 63) >> 6) {
+                    case 1: xp_rank_by_counting<1, RC>(R, nR, kj, rank); break;
+                    case 2: if constexpr (RC >= 2) xp_rank_by_counting<2, RC>(R, nR, kj, rank); break;
+                    case 3: if constexpr (RC >= 3) xp_rank_by_counting<3, RC>(R, nR, kj, rank); break;
+                    case 4: if constexpr (RC >= 4) xp_rank_by_counting<4, RC>(R, nR, kj, rank); break;
+                    default: xp_rank_by_counting<RC, RC>(R, nR, kj, rank); break;
+                }
+                wave_lds_sync();                           // every lane has read the unsorted list
+#pragma unroll
+                for (int ch = 0; ch < RC; ++ch)
+                    if ((uint32_t)ch * 64 + lane < nR) Rs[rank[ch]] = make_uint2(rx[ch], ryb[ch]);
+                wave_lds_sync();
+                // the sorted list in registers: lane l holds Rs[l], Rs[l + 64], ...
+#pragma unroll
+                for (int ch = 0; ch < RC; ++ch) {
+                    const uint32_t j = (uint32_t)ch * 64 + lane;
+                    rx[ch] = 0; ry[ch] = 0.f;
+                    if (j < nR) { const uint2 b = Rs[j]; rx[ch] = b.x; ry[ch] = __uint_as_float(b.y); }
                 }
             }
+            const uint32_t P2 = 1u << (31 - __builtin_clz(nR));                // largest power of two <= nR
             for (uint32_t ib = 0; ib < nL; ib += 64) {
-                // one row per lane: how many of its pairs pass
+                // one row per lane: the length of the passing prefix, by binary lifting
                 const bool vr = ib + lane < nL;
                 uint2 a = make_uint2(0, 0);
                 if (vr) a = L[ib + lane];
                 const float ay = __uint_as_float(a.y);
                 uint32_t cnt = 0;
+                if constexpr (WRITE) {
+                    for (uint32_t st = P2; st > 0; st >>= 1) {
+                        const uint32_t probe = cnt + st;
+                        if (probe <= nR) {
+                            const float s = ay + __uint_as_float(Rs[probe - 1].y);  // pk_compute.cpp:90
+                            if (s > p.eps) cnt = probe;                             // :91
+                        }
+                    }
+                } else {
 #pragma unroll 4
-                for (uint32_t j = 0; j < nR; ++j) {
-                    const float s = ay + __uint_as_float(R[j].y);              // pk_compute.cpp:90
-                    cnt += (s > p.eps) ? 1u : 0u;                              // :91
+                    for (uint32_t j = 0; j < nR; ++j) {
+                        const float s = ay + __uint_as_float(R[j].y);              // pk_compute.cpp:90
+                        cnt += (s > p.eps) ? 1u : 0u;                              // :91
+                    }
                 }
                 if (!vr) cnt = 0;
                 const uint32_t bk = a.x / RPB;
@@ -893,15 +959,11 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
                         uint2* dst = p.pool + (((unsigned long long)phi << 32) | plo);
                         const uint32_t ax = (uint32_t)__builtin_amdgcn_readlane((int)a.x, (int)r) * mulR;
                         const float ayr = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)a.y, (int)r));
-                        uint32_t done = 0;
 #pragma unroll
                         for (int ch = 0; ch < RC; ++ch) {
-                            if ((uint32_t)ch * 64 >= nR) break;
-                            const float s = ayr + ry[ch];                       // the count pass' operation, same operands
-                            const bool pass = s > p.eps;
-                            const uint64_t m = __ballot(pass);
-                            if (pass) dst[done + mbcnt(m)] = make_uint2(ax + rx[ch], __float_as_uint(s));
-                            done += (uint32_t)__popcll(m);
+                            if ((uint32_t)ch * 64 >= cr) break;
+                            const uint32_t j = (uint32_t)ch * 64 + lane;
+                            if (j < cr) dst[j] = make_uint2(ax + rx[ch], __float_as_uint(ayr + ry[ch]));   // :90, the row's passing prefix
                         }
                     }
                 }
