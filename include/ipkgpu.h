@@ -49,7 +49,7 @@ enum {
     IPKGPU_T_SCORE_LAUNCHES = 4,/* number of scoring passes (batches of groups) the sums cover */
     IPKGPU_T_SCORE_MAIN = 5,    /* the dominant kernel alone: list building + pair emission (score_stream_kernel /
                                    score_tiles_kernel), summed over batches */
-    IPKGPU_T_SCORE_REDUCE = 6   /* stream variant: per-bucket LDS max-reduce (reduce_buckets_kernel) */
+    IPKGPU_T_SCORE_REDUCE = 6   /* per-bucket LDS max-reduce (reduce_buckets_kernel / reduce_ranges_kernel) */
 };
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -64,9 +64,10 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx);
 const char* ipkgpu_last_error(const ipkgpu_ctx* ctx);
 
 /* Options: "workspace_bytes" (max bytes of per-group score tables resident at once; groups are
- * processed in batches that fit); "variant" (0 = auto: two-pass LDS max-reduce where available,
- * 1 = global-atomic max-reduce, 2 = force the two-pass form); "debug_flags" / "debug_pool_chunks"
- * (diagnostics and tests only).  Returns IPKGPU_ERR_INVALID for unknown names. */
+ * processed in batches that fit); "variant" (0 = auto: LDS max-reduce fed by the chunked pair pool, or by
+ * the exact-partition passes for AA k=6; 1 = global-atomic max-reduce; 2 = force the chunked pool;
+ * 3 = force the exact partition); "debug_flags" / "debug_pool_chunks" (diagnostics and tests only).
+ * Every variant yields identical results.  Returns IPKGPU_ERR_INVALID for unknown names. */
 int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value);
 
 /* ---- host helpers (no GPU needed) ------------------------------------------------------ */
