@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--alpha", type=float, default=0.0, help="override the column concentration")
     ap.add_argument("--output", default="db", choices=["db", "group"], help="db: key-major database shard; group: per-branch CSR")
     ap.add_argument("--cpu-groups", type=int, default=-1, help="groups timed on the CPU oracle (-1 = auto, 0 = skip)")
+    ap.add_argument("--variant", type=int, default=0, help="engine option 'variant' (0 = auto; diagnostics: 1 atomics, 2 chunked pool, 3 exact partition)")
     args = ap.parse_args()
 
     import torch
@@ -82,6 +83,8 @@ def main():
     t_gen = time.time() - t0
 
     eng = ipk_amd.Engine(local_rank)
+    if args.variant:
+        eng.set_option("variant", args.variant)
     if os.environ.get("IPKGPU_VARIANT"):
         eng.set_option("variant", int(os.environ["IPKGPU_VARIANT"]))   # diagnostics only
     if os.environ.get("IPKGPU_DEBUG_FLAGS"):

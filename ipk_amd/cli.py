@@ -60,7 +60,7 @@ def ipk():
 @click.option("--mapping", type=click.Path(exists=True), required=True,
               help="TSV: AR node label <TAB> branch post-order id, one line per ghost node")
 @click.option("--num-tree-nodes", type=int, default=0, help="node count of the original tree (MIF0's N); default 2*branches+1")
-@click.option("--device", type=int, default=0, show_default=True, help="GPU index")
+@click.option("--device", type=int, default=None, help="GPU index [0; LOCAL_RANK under torchrun]")
 def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, alpha, categories, k, model, convert_uo,
           no_reduction, reduction_ratio, omega, filter_, mu, ghosts, use_unrooted, merge_branches, ar_dir, ar_only,
           ar_config, keep_positions, uncompressed, threads, output, on_disk, mapping, num_tree_nodes, device):
@@ -94,37 +94,72 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
     if not labels:
         raise click.UsageError("the mapping selects no ghost nodes")
 
+    # several GPUs: one process per GPU (torchrun); branch groups are split into contiguous ranges of the group
+    # order, every rank scores its range, the k-mer-keyed exchange (RCCL) leaves rank r with the k-mers code % P == r
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dist = None
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(device)
+        own_group = not dist.is_initialized()
+        if own_group:
+            dist.init_process_group(os.environ.get("IPK_DIST_BACKEND", "nccl"))
+    all_branches = list(branches)
+    group_order = list(dict.fromkeys(all_branches))                        # first-seen order (db_builder.cpp:524-553)
+    g0, g1 = distributed.shard_range(len(group_order), world, rank)
+    mine = set(group_order[g0:g1])
+    sel = [i for i, b in enumerate(all_branches) if b in mine]
+    labels, branches = [labels[i] for i in sel], [all_branches[i] for i in sel]
+
     t0 = time.time()
     arp = AncestralProbs(probs[0], sigma)
-    mats = arp.read(labels, n_threads=max(1, threads))
+    mats = arp.read(labels, n_threads=max(1, threads)) if labels else np.zeros((0, arp.sites, sigma), np.float32)
     t_load = time.time() - t0
     log_eps = ipk_amd.log_threshold(omega, sigma, k)
     eng = ipk_amd.Engine(device)
     t0 = time.time()
-    db, parts = distributed.build_db_shard(eng, mats, np.array(branches, dtype=np.uint32), k, log_eps, sigma)
+    if world > 1:
+        import torch
+        mats = torch.from_numpy(np.ascontiguousarray(mats)).cuda()
+    db, parts = distributed.build_db_shard(eng, mats, np.array(branches, dtype=np.uint32), k, log_eps, sigma, dist, world, rank)
     t_score = time.time() - t0
-    n_nodes = num_tree_nodes or 2 * len(set(branches)) + 1
+    n_nodes = num_tree_nodes or 2 * len(group_order) + 1
     t0 = time.time()
     if filter_ == "mif0":
         db.filter_mif0(eng, n_nodes, ipk_amd.score_threshold(omega, sigma, k))
         fv, order = db.filter_values().copy(), db.filter_order().copy()
-    else:                                                   # random_filter: filter.cpp:133-146 (engine 42)
-        fv = np.random.default_rng(42).random(db.num_keys).astype(np.float32)
-        order = np.lexsort((db.keys(), fv))
+    else:
+        # random_filter (filter.cpp:122-145) draws uniform(0, 1) from std::default_random_engine(42) in the hash map's
+        # iteration order, which no other build reproduces; here: one fixed draw per k-mer CODE, so the file does not
+        # depend on how the k-mers are sharded
+        fv = (dbfile.splitmix_unit(db.keys()) if db.num_keys else np.zeros(0)).astype(np.float32)
+        order = np.argsort(dbfile.filter_sort_code(fv, db.keys()), kind="stable")
     t_filter = time.time() - t0
     newick = open(reftree).read().strip() if reftree and os.path.exists(reftree) else ""
     br, sc = db.entries()
     t0 = time.time()
-    dbfile.write_db(output, "DNA" if sigma == 4 else "AA", [], newick, k, omega, db.keys(), db.key_offsets(), br, sc, fv, order)
+    totals = distributed.write_db_file(output, "DNA" if sigma == 4 else "AA", [], newick, k, omega, db.keys(), db.key_offsets(),
+                                       br, sc, fv, order, workdir, dist, world, rank)
     t_write = time.time() - t0
-    if verbosity:
+    emitted = parts.emitted
+    if world > 1:
+        import torch
+        e = torch.tensor([emitted], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(e)
+        emitted = int(e.item())
+    if verbosity and rank == 0:
         # the reference prints the same three stage timers (db_builder.cpp:236,290,336)
-        click.echo(f"Loaded {len(labels)} node matrices ({arp.sites} sites) in {t_load * 1e3:.0f} ms")
-        click.echo(f"Computation time: {t_score * 1e3:.0f} ms ({parts.emitted} scored phylo-k-mers)")
+        click.echo(f"Loaded {len(labels)} node matrices ({arp.sites} sites) in {t_load * 1e3:.0f} ms" + (f" on each of {world} ranks" if world > 1 else ""))
+        click.echo(f"Computation time: {t_score * 1e3:.0f} ms ({emitted} scored phylo-k-mers)")
         click.echo(f"Filtering time: {t_filter * 1e3:.0f} ms")
         click.echo(f"Merge time: {t_write * 1e3:.0f} ms")
-        click.echo(f"Output: {output} ({db.num_keys} k-mers, {db.num_entries} entries)")
+        click.echo(f"Output: {output} ({totals[0]} k-mers, {totals[1]} entries)")
     db.free(); parts.free(); eng.close(); arp.close()
+    if world > 1 and own_group:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -79,3 +79,48 @@ def read_db(path):
     hdr = dict(sequence_type=st, tree_index=[(int(a), float(b)) for a, b in ti], newick=newick, kmer_size=k,
                omega=omega, total_num_kmers=nk, total_num_entries=ne)
     return hdr, recs
+
+
+# ---- several GPUs: every rank owns the k-mers with code % P == rank ---------------------------------
+# Filter values are per k-mer, so each rank computes them on its own shard; the final file is the merge of
+# the P shards by filter value -- the role merge_stage2 plays for the reference's on-disk batches
+# (db_builder.cpp:392-458: batch files opened together, smallest filter value written next).
+
+def filter_sort_code(filter_values, keys):
+    """The engine's filter order as one integer per k-mer: order-preserving code of the float32 filter value, ties by
+    ascending key (ipk_amd/csrc/kernels_filter.hpp, filter_sortkey_kernel)."""
+    u = np.asarray(filter_values, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    code = np.where(u & np.uint64(0x80000000), ~u & np.uint64(0xFFFFFFFF), u | np.uint64(0x80000000))
+    return (code << np.uint64(32)) | np.asarray(keys, dtype=np.uint64)
+
+
+def splitmix_unit(keys):
+    """A reproducible value in [0, 1) per k-mer code (the `random` filter): independent of the sharding."""
+    x = np.asarray(keys, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    x = x ^ (x >> np.uint64(31))
+    return (x >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+
+def write_shard(path, keys, key_offsets, branches, scores, filter_values):
+    """One rank's shard (ascending keys) with its filter values, as plain arrays for merge_shards."""
+    with open(path, "wb") as fh:
+        np.savez(fh, keys=np.asarray(keys, dtype=np.uint32), off=np.asarray(key_offsets, dtype=np.uint64),
+                 br=np.asarray(branches, dtype=np.uint32), sc=np.asarray(scores, dtype=np.float32).view(np.uint32),
+                 fv=np.asarray(filter_values, dtype=np.float32))
+
+
+def merge_shards(path, sequence_type, tree_index, newick, kmer_size, omega, shard_paths):
+    """Merges the ranks' shards by (filter value, key) into one database file, identical to the file a single
+    GPU writes for the same input.  Returns (total k-mers, total entries)."""
+    keys, lens, br, sc, fv = [], [], [], [], []
+    for sp in shard_paths:
+        z = np.load(sp)
+        keys.append(z["keys"]); lens.append(np.diff(z["off"].astype(np.int64))); br.append(z["br"]); sc.append(z["sc"]); fv.append(z["fv"])
+    keys = np.concatenate(keys); lens = np.concatenate(lens); fv = np.concatenate(fv)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    order = np.argsort(filter_sort_code(fv, keys), kind="stable")
+    write_db(path, sequence_type, tree_index, newick, kmer_size, omega, keys, off, np.concatenate(br),
+             np.concatenate(sc).view(np.float32), fv, order)
+    return len(keys), int(off[-1])

@@ -132,3 +132,29 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
     pa.emitted += pb.emitted
     pb.free()
     return db, pa
+
+
+def write_db_file(path, sequence_type, tree_index, newick, kmer_size, omega, keys, key_offsets, branches, scores,
+                  filter_values, order, workdir, dist=None, world=1, rank=0):
+    """Database file from the ranks' shards.  One rank: written directly in its filter order.  Several ranks: every
+    rank drops its shard into workdir/shards (the reference's on-disk mode leaves its batches in workdir/hashmaps the
+    same way, db_builder.cpp:460-464), rank 0 merges them by filter value (dbfile.merge_shards).
+    Returns (total k-mers, total entries) on the writing rank, None elsewhere."""
+    import os
+    from . import dbfile
+    if world == 1:
+        dbfile.write_db(path, sequence_type, tree_index, newick, kmer_size, omega, keys, key_offsets, branches, scores,
+                        filter_values, order)
+        return len(keys), int(key_offsets[-1]) if len(key_offsets) else 0
+    sdir = os.path.join(workdir, "shards")
+    os.makedirs(sdir, exist_ok=True)
+    mine = os.path.join(sdir, f"shard{rank}.npz")
+    dbfile.write_shard(mine, keys, key_offsets, branches, scores, filter_values)
+    dist.barrier()
+    out = None
+    if rank == 0:
+        paths = [os.path.join(sdir, f"shard{r}.npz") for r in range(world)]
+        out = dbfile.merge_shards(path, sequence_type, tree_index, newick, kmer_size, omega, paths)
+    dist.barrier()
+    os.remove(mine)
+    return out

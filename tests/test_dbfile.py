@@ -26,3 +26,32 @@ def test_round_trip(tmp_path):
     assert all(recs[i][1] <= recs[i + 1][1] for i in range(len(recs) - 1))
     for r in recs[:50]:
         assert [(int(b), int(s)) for b, s in zip(r[2], r[3].view(np.uint32))] == full[r[0]]
+
+
+def test_merge_of_rank_shards_equals_the_single_writer(tmp_path):
+    """Several GPUs: rank r owns the k-mers with code % P == r and its own filter values; merging the shard files by
+    (filter value, key) must give the file one GPU writes (dbfile.merge_shards, the role of merge_stage2)."""
+    rng = np.random.default_rng(5)
+    n = 500
+    keys = np.sort(rng.choice(4 ** 8, size=n, replace=False)).astype(np.uint32)
+    lens = rng.integers(1, 6, size=n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    br = rng.integers(0, 40, size=int(off[-1])).astype(np.uint32)
+    sc = (-rng.random(int(off[-1])) * 5).astype(np.float32)
+    fv = np.round(rng.normal(size=n), 1).astype(np.float32)          # coarse values: plenty of ties, both signs
+    fv[::50] = 0.0; fv[25::50] = -0.0                                 # and both zeros
+    order = np.argsort(dbfile.filter_sort_code(fv, keys), kind="stable")
+    one = tmp_path / "one.db"
+    dbfile.write_db(one, "DNA", [(3, 0.5)], "(a,b);", 8, 1.5, keys, off, br, sc, fv, order)
+    for world in (2, 3):
+        paths = []
+        for r in range(world):
+            m = keys % world == r
+            ml = lens[m]
+            idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in np.nonzero(m)[0]]).astype(np.int64)
+            so = np.concatenate([[0], np.cumsum(ml)]).astype(np.uint64)
+            paths.append(tmp_path / f"s{world}_{r}.npz")
+            dbfile.write_shard(paths[-1], keys[m], so, br[idx], sc[idx], fv[m])
+        merged = tmp_path / f"merged{world}.db"
+        assert dbfile.merge_shards(merged, "DNA", [(3, 0.5)], "(a,b);", 8, 1.5, paths) == (n, int(off[-1]))
+        assert open(merged, "rb").read() == open(one, "rb").read()
