@@ -488,6 +488,25 @@ int launch_xp(ipkgpu_ctx* ctx, const XpParams& xp, uint32_t n_wg)
         return IPKGPU_OK;
     }
 }
+template <int SIGMA, int K, bool WRITE>
+int launch_xp_overflow(ipkgpu_ctx* ctx, const XpParams& xp)
+{
+    constexpr uint32_t TBL = xp_tbl<SIGMA, K>();
+    if constexpr (TBL == 0 || ipow(SIGMA, K - K / 2) <= (uint32_t)fast_cap<SIGMA, K>()) {
+        (void)ctx; (void)xp;
+        return IPKGPU_OK;                           // lists can never overflow
+    } else {
+        constexpr size_t lds = TileGeo<SIGMA, K, 1>::HEAD_BYTES + (size_t)wave_scratch_entries<SIGMA, K, 1 << 30>() * 8;
+        static_assert(lds + 64 <= 160 * 1024, "big-list (exact partition) LDS budget");
+        auto kern = score_overflow_xp_kernel<SIGMA, K, TBL, WRITE>;
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 64)));
+        hipLaunchKernelGGL(kern, dim3(ctx->num_cu * per_cu), dim3(OVF_NW * 64), lds, ctx->stream, xp);
+        HIP_TRY(ctx, hipGetLastError());
+        return IPKGPU_OK;
+    }
+}
 template <int SIGMA, int K>
 int launch_xp_reduce(ipkgpu_ctx* ctx, uint32_t n_gb, uint32_t S, uint64_t T, const uint64_t* off, uint32_t* table)
 {
@@ -609,6 +628,13 @@ int dispatch_xp(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const XpParams& xp,
 #undef M_XP
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
 }
+int dispatch_xp_overflow(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const XpParams& xp, bool write)
+{
+#define M_XO(S_, K_) return write ? launch_xp_overflow<S_, K_, true>(ctx, xp) : launch_xp_overflow<S_, K_, false>(ctx, xp)
+    IPK_DISPATCH(sigma, k, M_XO);
+#undef M_XO
+    return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+}
 int dispatch_xp_reduce(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t n_gb, uint32_t S, uint64_t T, const uint64_t* off, uint32_t* table)
 {
 #define M_XR(S_, K_) return launch_xp_reduce<S_, K_>(ctx, n_gb, S, T, off, table)
@@ -717,10 +743,14 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     // four rounds of resident workgroups balance the tail; a unit costs only its NB counters
     const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((slots * 4) / gb, tiles_per_mat));
     const uint64_t n_gb = (uint64_t)gb * XNB;
-    const uint64_t n_units = n_gb * S;
+    const uint32_t stride = S + 1;                           // slot S of every (group, bucket): the big-list windows
+    const uint64_t n_units = n_gb * stride;
     if (n_gb > 0x7fffffffull || (uint64_t)gb * S > 0x7fffffffull) return fail(ctx, IPKGPU_ERR_INVALID, "batch too large for one launch");
     RC_TRY(ensure(ctx, ctx->gbcnt, n_units * 4));
     RC_TRY(ensure(ctx, ctx->gboff, (n_units + 1) * 8));
+    RC_TRY(ensure(ctx, ctx->gbcur, n_gb * 4));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->gbcnt.p, 0, n_units * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->gbcur.p, 0, n_gb * 4, ctx->stream));
 
     XpParams xp;
     StreamParams& sp = xp.s;
@@ -733,16 +763,19 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     sp.flags = 0;
     xp.cnt = ctx->gbcnt.as<uint32_t>();
     xp.off = ctx->gboff.as<uint64_t>();
+    xp.stride = stride;
+    xp.ovcur = ctx->gbcur.as<uint32_t>();
 
     Stopwatch sw(ctx->stream);
     const int ev_a = sw.mark();
     RC_TRY(dispatch_xp(ctx, pl.sigma, pl.k, xp, gb * S, false));
+    const int ev_a2 = sw.mark();
+    RC_TRY(dispatch_xp_overflow(ctx, pl.sigma, pl.k, xp, false));          // reads the queue length on the device
     RC_TRY(scan_u32(ctx, xp.cnt, n_units, ctx->gboff.as<uint64_t>()));
     const int ev_b = sw.mark();
+    (void)ev_b;
     uint64_t total = 0;
-    uint32_t n_ovf = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->gboff.as<uint64_t>() + n_units, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&n_ovf, p.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     {
         size_t free_b = 0, total_b = 0;
@@ -755,13 +788,14 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     sp.pool = ctx->pool.as<uint2>();
     const int ev_c = sw.mark();
     RC_TRY(dispatch_xp(ctx, pl.sigma, pl.k, xp, gb * S, true));
+    const int ev_d0 = sw.mark();
+    RC_TRY(dispatch_xp_overflow(ctx, pl.sigma, pl.k, xp, true));
     const int ev_d = sw.mark();
-    RC_TRY(dispatch_xp_reduce(ctx, pl.sigma, pl.k, (uint32_t)n_gb, S, pl.table_size, ctx->gboff.as<uint64_t>(), ctx->table.as<uint32_t>()));
+    RC_TRY(dispatch_xp_reduce(ctx, pl.sigma, pl.k, (uint32_t)n_gb, stride, pl.table_size, ctx->gboff.as<uint64_t>(), ctx->table.as<uint32_t>()));
     const int ev_e = sw.mark();
-    if (n_ovf > 0) RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));      // global atomics on the finished tables
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->mask_valid = true;
-    ctx->acc_main_ms += sw.ms(ev_a, ev_b) + sw.ms(ev_c, ev_d);
+    ctx->acc_main_ms += sw.ms(ev_a, ev_a2) + sw.ms(ev_c, ev_d0);
     ctx->acc_reduce_ms += sw.ms(ev_d, ev_e);
     return IPKGPU_OK;
 }

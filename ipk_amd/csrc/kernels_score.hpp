@@ -806,8 +806,10 @@ __device__ __forceinline__ void xp_rank_by_counting(const uint2* R, uint32_t n, 
 
 struct XpParams {
     StreamParams s;                // pool_next / desc / pool_ovf unused
-    uint32_t* cnt;                 // [(group * NB + bucket) * S + segment]   (count pass output)
-    const uint64_t* off;           // exclusive scan of cnt                   (write pass input)
+    uint32_t* cnt;                 // [(group * NB + bucket) * stride + segment]   (count pass output)
+    const uint64_t* off;           // exclusive scan of cnt                        (write pass input)
+    uint32_t stride;               // S + 1: segment S of every (group, bucket) belongs to the big-list windows
+    uint32_t* ovcur;               // [group * NB + bucket] pairs the big-list write pass has placed so far
 };
 
 template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL, bool WRITE>
@@ -834,9 +836,9 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
     const uint32_t total_tiles = nm * p.tiles_per_mat;
     const uint32_t t_lo = (uint32_t)(((uint64_t)total_tiles * seg) / p.S);
     const uint32_t t_hi = (uint32_t)(((uint64_t)total_tiles * (seg + 1)) / p.S);
-    const size_t ub = (size_t)g * NB * p.S + seg;           // this unit's slot of bucket b: ub + b * S
+    const size_t ub = (size_t)g * NB * xp.stride + seg;     // this unit's slot of bucket b: ub + b * stride
     for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) {
-        if constexpr (WRITE) cur[b] = xp.off[ub + (size_t)b * p.S];
+        if constexpr (WRITE) cur[b] = xp.off[ub + (size_t)b * xp.stride];
         else cur[b] = 0;
     }                                                       // (the first tile's barriers order this before any use)
 
@@ -972,11 +974,91 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
     }
     if constexpr (!WRITE) {
         __syncthreads();
-        for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) xp.cnt[ub + (size_t)b * p.S] = cur[b];
+        for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) xp.cnt[ub + (size_t)b * xp.stride] = cur[b];
         // wave sum of the per-lane counts
         for (int o = 32; o > 0; o >>= 1) emitted += __shfl_down(emitted, o, 64);
         if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);
     }
+}
+
+// Big-list windows of the exact-partition variant (queued by the count pass of score_xp_kernel): same cooperative
+// shape as score_overflow_kernel, run twice like the fast path.  Their pairs take segment S of every (group, bucket):
+// the count pass adds a row's passing pairs to that slot (one global atomic per row), the write pass reserves the
+// row's run behind the slot's offset and writes it.  So these pairs, too, are max-reduced in LDS, and nothing
+// touches the tables after the reduce pass.
+template <int SIGMA, int K, uint32_t TBL, bool WRITE>
+__global__ __launch_bounds__(OVF_NW * 64) void score_overflow_xp_kernel(XpParams xp)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const StreamParams& p = xp.s;
+    constexpr int CAPF = 1 << 30;
+    constexpr uint32_t T = ipow(SIGMA, K);
+    constexpr uint32_t NB = (T + TBL - 1) / TBL;
+    constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
+    static_assert(TBL % mulR == 0, "a row of the final join must stay inside one bucket");
+    constexpr uint32_t RPB = TBL / mulR;
+    using TG = TileGeo<SIGMA, K, 1>;
+    __shared__ uint32_t sh_n[2];
+    float* cols = reinterpret_cast<float*>(smem);
+    float* best = cols + TG::COLS_F;
+    uint2* scratch = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
+    const uint32_t n = *p.ovf_count;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long emitted = 0;
+    for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
+        const unsigned long long e = p.ovf_queue[q];
+        const uint32_t mat = (uint32_t)(e >> 32), start = (uint32_t)e;
+        const uint32_t g = p.mat_slot[mat];
+        __syncthreads();                                                       // previous window's lists consumed
+        const float* src = p.logp + ((size_t)mat * p.sites + start) * SIGMA;
+        for (uint32_t i = threadIdx.x; i < K * SIGMA; i += OVF_NW * 64) cols[i] = src[i];
+        const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + start;
+        for (uint32_t i = threadIdx.x; i <= K; i += OVF_NW * 64) best[i] = bsrc[i];
+        __syncthreads();
+        const uint2 *L = scratch, *R = scratch + Geo<SIGMA, K / 2, CAPF>::CAPH;
+        if (wave == 0) {
+            WinCtx c{cols, best, 0};
+            uint32_t nL = 0, nR = 0;
+            build_halves<SIGMA, K, CAPF>(c, p.eps, scratch, L, nL, R, nR);      // cannot overflow at full capacity
+            if (lane == 0) { sh_n[0] = nL; sh_n[1] = nR; }
+        }
+        __syncthreads();
+        const uint32_t nL = sh_n[0], nR = sh_n[1];
+        if (nL == 0 || nR == 0) continue;
+        for (uint32_t i = wave; i < nL; i += OVF_NW) {                         // rows of L dealt to the waves
+            const uint2 a = L[i];
+            const uint32_t bk = a.x / RPB;
+            const size_t slot = ((size_t)g * NB + bk) * xp.stride + (xp.stride - 1);
+            uint32_t c = 0;
+            for (uint32_t jb = 0; jb < nR; jb += 64) {
+                const uint32_t j = jb + lane;
+                const float s = __uint_as_float(a.y) + __uint_as_float(j < nR ? R[j].y : 0u);   // pk_compute.cpp:90
+                c += (uint32_t)__popcll(__ballot(j < nR && s > p.eps));                           // :91
+            }
+            if (c == 0) continue;
+            if constexpr (!WRITE) {
+                if (lane == 0) atomicAdd(&xp.cnt[slot], c);
+                emitted += c;
+            } else {
+                uint32_t rel = 0;
+                if (lane == 0) rel = atomicAdd(&xp.ovcur[(size_t)g * NB + bk], c);
+                rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
+                uint2* dst = p.pool + xp.off[slot] + rel;
+                uint32_t done = 0;
+                for (uint32_t jb = 0; jb < nR; jb += 64) {
+                    const uint32_t j = jb + lane;
+                    uint2 b = make_uint2(0, 0);
+                    if (j < nR) b = R[j];
+                    const float s = __uint_as_float(a.y) + __uint_as_float(b.y);
+                    const bool pass = j < nR && s > p.eps;
+                    const uint64_t m = __ballot(pass);
+                    if (pass) dst[done + mbcnt(m)] = make_uint2(a.x * mulR + b.x, __float_as_uint(s));
+                    done += (uint32_t)__popcll(m);
+                }
+            }
+        }
+    }
+    if (!WRITE && lane == 0 && emitted) atomicAdd(p.emitted, emitted);
 }
 
 // xp pass 3: one workgroup per (group, bucket); its pairs are ONE contiguous range of the pool
@@ -992,7 +1074,7 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(const uint2* __restri
     const uint32_t g = gb / NB, b = gb - g * NB;
     const uint64_t key0 = (uint64_t)b * TBL;
     const uint32_t nslots = (uint32_t)min((uint64_t)TBL, T - key0);
-    const uint64_t r0 = off[(size_t)gb * S], r1 = off[(size_t)gb * S + S];
+    const uint64_t r0 = off[(size_t)gb * S], r1 = off[(size_t)gb * S + S];     // S = slots per (group, bucket) in the scan
     constexpr int PER = 4;
     uint2 v[PER];
     uint64_t i = r0 + threadIdx.x;
