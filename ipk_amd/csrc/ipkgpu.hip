@@ -64,7 +64,11 @@ struct ipkgpu_ctx {
     DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
     DevBuf mask;                 // occupancy bits of ctx->table ([groups in batch][mask_words]) when mask_valid
     bool mask_valid = false;
-    uint64_t mask_words = 0;
+    uint64_t mask_words = 0;     // 2 * ceil(table_size / 64): rows padded to whole 64-slot blocks
+    // compressed table form (exact-partition variant on sparse key spaces; comp_table.hpp): no dense ctx->table
+    bool table_compressed = false;
+    DevBuf rank, ucnt;
+    uint32_t comp_nb = 0, comp_stride = 0, comp_tbl = 0;
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
     double acc_main_ms = 0, acc_reduce_ms = 0;   // dominant scoring kernel / LDS reduce pass of the current call
     // caching allocator for result buffers: hipMalloc/hipFree of multi-GB blocks costs 10-100 ms, so
@@ -275,7 +279,8 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
                       &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
-                      &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->mask};
+                      &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->mask,
+                      &ctx->rank, &ctx->ucnt};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
     if (ctx->small) (void)hipFree(ctx->small);
@@ -507,24 +512,26 @@ int launch_xp_overflow(ipkgpu_ctx* ctx, const XpParams& xp)
         return IPKGPU_OK;
     }
 }
-template <int SIGMA, int K>
+template <int SIGMA, int K, bool COMPRESS>
 int launch_xp_reduce(ipkgpu_ctx* ctx, uint32_t n_gb, uint32_t S, uint64_t T, const uint64_t* off, uint32_t* table)
 {
     constexpr uint32_t TBL = xp_tbl<SIGMA, K>();
     if constexpr (TBL == 0) { (void)n_gb; (void)S; (void)T; (void)off; (void)table; return fail(ctx, IPKGPU_ERR_INVALID, "exact-partition variant unsupported"); }
     else {
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+        static_assert(!COMPRESS || NB == 1 || TBL % 64 == 0, "a 64-slot block must not straddle two buckets");
         constexpr int NT = TBL <= 16384 ? 512 : 1024;
-        constexpr size_t lds = (size_t)TBL * 4;
-        auto kern = reduce_ranges_kernel<TBL, NT>;
+        constexpr size_t lds = (size_t)TBL * 4 + (COMPRESS ? ((TBL + 63) / 64 + 1) * 4 : 0);
+        auto kern = reduce_ranges_kernel<TBL, NT, COMPRESS>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(), off, S, NB, T, table,
-                           ctx->mask.as<uint32_t>(), ctx->mask_words);
+                           ctx->mask.as<uint32_t>(), ctx->mask_words, ctx->rank.as<uint32_t>(), ctx->ucnt.as<uint32_t>());
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
     }
 }
+template <int SIGMA, int K> uint32_t xp_tbl_value() { return xp_tbl<SIGMA, K>(); }
 
 #define IPK_DISPATCH(SIGMA_V, K_V, EXPR_MACRO)                                         \
     do {                                                                               \
@@ -635,12 +642,28 @@ int dispatch_xp_overflow(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const XpPa
 #undef M_XO
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
 }
-int dispatch_xp_reduce(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t n_gb, uint32_t S, uint64_t T, const uint64_t* off, uint32_t* table)
+int dispatch_xp_reduce(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t n_gb, uint32_t S, uint64_t T, const uint64_t* off, uint32_t* table,
+                       bool compress)
 {
-#define M_XR(S_, K_) return launch_xp_reduce<S_, K_>(ctx, n_gb, S, T, off, table)
+#define M_XR(S_, K_) return compress ? launch_xp_reduce<S_, K_, true>(ctx, n_gb, S, T, off, table) : launch_xp_reduce<S_, K_, false>(ctx, n_gb, S, T, off, table)
     IPK_DISPATCH(sigma, k, M_XR);
 #undef M_XR
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+}
+uint32_t xp_bucket_slots(uint32_t sigma, uint32_t k)
+{
+#define M_XT(S_, K_) return xp_tbl_value<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_XT);
+#undef M_XT
+    return 0;
+}
+CompTable comp_table(const ipkgpu_ctx* ctx)
+{
+    CompTable ct;
+    ct.mask = ctx->mask.as<uint32_t>(); ct.rank = ctx->rank.as<uint32_t>(); ct.pool = ctx->pool.as<uint2>();
+    ct.off = ctx->gboff.as<uint64_t>(); ct.mask_words = ctx->mask_words;
+    ct.NB = ctx->comp_nb; ct.stride = ctx->comp_stride; ct.TBL = ctx->comp_tbl;
+    return ct;
 }
 
 int dispatch_score(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScoreParams& p)
@@ -733,7 +756,7 @@ int scan_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out);
 
 // Exact-partition variant of one batch (kernels_score.hpp): count -> scan -> write -> reduce -> big-list windows.
 // ctx->gm holds the batch's group -> matrices CSR; p carries the shared counters and the big-list queue.
-int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t gb, uint32_t nb, ScoreParams& p, uint32_t XNB)
+int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t gb, uint32_t nb, ScoreParams& p, uint32_t XNB, bool compress)
 {
     (void)nb;
     const uint32_t tiles_per_mat = (pl.nwin + XP_TW - 1) / XP_TW;
@@ -791,10 +814,19 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     const int ev_d0 = sw.mark();
     RC_TRY(dispatch_xp_overflow(ctx, pl.sigma, pl.k, xp, true));
     const int ev_d = sw.mark();
-    RC_TRY(dispatch_xp_reduce(ctx, pl.sigma, pl.k, (uint32_t)n_gb, stride, pl.table_size, ctx->gboff.as<uint64_t>(), ctx->table.as<uint32_t>()));
+    if (compress) {
+        RC_TRY(ensure(ctx, ctx->rank, (size_t)gb * (ctx->mask_words / 2) * 4));
+        RC_TRY(ensure(ctx, ctx->ucnt, n_gb * 4));
+    } else {
+        RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 4));
+    }
+    RC_TRY(dispatch_xp_reduce(ctx, pl.sigma, pl.k, (uint32_t)n_gb, stride, pl.table_size, ctx->gboff.as<uint64_t>(),
+                              compress ? nullptr : ctx->table.as<uint32_t>(), compress));
     const int ev_e = sw.mark();
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->mask_valid = true;
+    ctx->table_compressed = compress;
+    ctx->comp_nb = XNB; ctx->comp_stride = stride; ctx->comp_tbl = xp_bucket_slots(pl.sigma, pl.k);
     ctx->acc_main_ms += sw.ms(ev_a, ev_a2) + sw.ms(ev_c, ev_d0);
     ctx->acc_reduce_ms += sw.ms(ev_d, ev_e);
     return IPKGPU_OK;
@@ -814,7 +846,6 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) { mat_list_h[nb++] = i; mat_slot_h[i] = pl.slot_of[i] - g0; }
     }
     RC_TRY(ensure(ctx, ctx->idx, (size_t)n_mats * 8));
-    RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 4));
     RC_TRY(ensure(ctx, ctx->ovfq, (size_t)nb * pl.nwin * 8));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->idx.p, idx_host.data(), (size_t)n_mats * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // idx_host is pageable and reused by the next batch
@@ -835,15 +866,22 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     p.flags = (uint32_t)(ctx->opt_variant == 99 ? 1 : 0);
     p.mask = nullptr; p.mask_words = 0;
     ctx->mask_valid = false;
+    ctx->table_compressed = false;
     HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
     const uint32_t NBK = stream_buckets(pl.sigma, pl.k);
     const uint32_t XNB = xp_buckets(pl.sigma, pl.k);
     // variant 0 = default: stream where its per-wave chunk state fits (all DNA k, AA k <= 5), exact partition for
     // AA k=6; 1 = global atomics, 2 = stream (diagnostic flags honoured), 3 = exact partition wherever it exists
-    const bool use_xp = XNB != 0 && (ctx->opt_variant == 3 || (ctx->opt_variant == 0 && NBK == 0));
+    //                 4 = exact partition with the compressed table form (the default for AA k=6: 28 % occupancy)
+    const bool use_xp = XNB != 0 && (ctx->opt_variant == 3 || ctx->opt_variant == 4 || (ctx->opt_variant == 0 && NBK == 0));
+    const bool xp_compress = use_xp && ctx->opt_variant != 3;
     const bool use_stream = !use_xp && NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
     const uint32_t SNW = stream_waves(pl.sigma, pl.k), STW = stream_tile(pl.sigma, pl.k);
     const uint32_t s_tiles_per_mat = (pl.nwin + STW - 1) / STW;
+    if (!xp_compress) {
+        RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 4));
+        p.table = ctx->table.p;
+    }
     if (!use_stream && !use_xp) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->table.p, 0, (size_t)gb * pl.table_size * 4, ctx->stream));
         Stopwatch sw(ctx->stream);
@@ -870,10 +908,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     HIP_TRY(ctx, hipMemcpyAsync(ctx->gm.p, gm.data(), gm.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // occupancy bits of the tables: written by the LDS reduce pass, kept current by the big-list kernel, read by km_count
-    ctx->mask_words = (pl.table_size + 31) / 32;
+    ctx->mask_words = 2 * ((pl.table_size + 63) / 64);
     RC_TRY(ensure(ctx, ctx->mask, (size_t)gb * ctx->mask_words * 4));
     p.mask = ctx->mask.as<uint32_t>(); p.mask_words = ctx->mask_words;
-    if (use_xp) return score_batch_xp(ctx, pl, logp_dev, gb, nb, p, XNB);
+    if (use_xp) return score_batch_xp(ctx, pl, logp_dev, gb, nb, p, XNB, xp_compress);
 
     // Segments (workgroups) per group.  More workgroups balance the tail of the persistent kernel, but every
     // wavefront keeps one open chunk per key bucket, so workgroups x waves x buckets must stay well below
@@ -1084,8 +1122,12 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
         res->score_launches += 1;
 
         const uint32_t n_chunks = gb * cpg;
-        hipLaunchKernelGGL(count_chunks_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream,
-                           ctx->table.as<uint32_t>(), pl.table_size, cpg, ctx->counts.as<uint32_t>());
+        if (ctx->mask_valid)
+            hipLaunchKernelGGL(count_chunks_mask_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream,
+                               ctx->mask.as<uint32_t>(), ctx->mask_words, cpg, ctx->counts.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(count_chunks_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream,
+                               ctx->table.as<uint32_t>(), pl.table_size, cpg, ctx->counts.as<uint32_t>());
         hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                            ctx->counts.as<uint32_t>(), (uint64_t)n_chunks, total_entries, ctx->offsets.as<uint64_t>());
         hipLaunchKernelGGL(gather_offsets_kernel, dim3((gb + 1 + 255) / 256), dim3(256), 0, ctx->stream,
@@ -1112,7 +1154,15 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
             ctx_release(ctx, res->d_scores);
             res->d_keys = nk; res->d_scores = ns; res->cap = new_cap;
         }
-        if (sigma == 4)
+        if (ctx->table_compressed) {
+            const CompTable ct = comp_table(ctx);
+            if (sigma == 4)
+                hipLaunchKernelGGL(write_chunks_c_kernel<4>, dim3(n_chunks), dim3(256), 0, ctx->stream, ct,
+                                   pl.table_size, cpg, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);
+            else
+                hipLaunchKernelGGL(write_chunks_c_kernel<20>, dim3(n_chunks), dim3(256), 0, ctx->stream, ct,
+                                   pl.table_size, cpg, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);
+        } else if (sigma == 4)
             hipLaunchKernelGGL(write_chunks_kernel<4>, dim3(n_chunks), dim3(256), 0, ctx->stream, ctx->table.as<uint32_t>(),
                                pl.table_size, cpg, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);
         else
@@ -1478,9 +1528,15 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         HIP_TRY(ctx, hipMemcpyAsync(b.owner_off.data(), ctx->goff.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.entries, std::max<uint64_t>(b.owner_off[P], 1) * 8));
-        hipLaunchKernelGGL(km_write_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
-                           ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
-                           ctx->offsets.as<uint64_t>(), b.entries);
+        if (ctx->table_compressed) {
+            const uint64_t per_xcd = (((T + 63) / 64) + 7) / 8;
+            hipLaunchKernelGGL(km_write_c_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
+                               comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
+                               ctx->offsets.as<uint64_t>(), b.entries);
+        } else
+            hipLaunchKernelGGL(km_write_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
+                               ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
+                               ctx->offsets.as<uint64_t>(), b.entries);
         HIP_TRY(ctx, hipGetLastError());
         ev_compact.push_back({s1, sw.mark()});
     }

@@ -1,6 +1,7 @@
 // kernels_compact.hpp -- dense per-group tables -> group-major CSR (sorted keys per branch group).
 #pragma once
 #include "dcla_device.hpp"
+#include "comp_table.hpp"
 
 namespace ipkgpu {
 
@@ -101,6 +102,53 @@ __global__ __launch_bounds__(256) void write_chunks_kernel(const uint32_t* __res
     }
 }
 
+
+// ---- the same two steps from the occupancy bits / the compressed table form ---------------------------
+// counts[g * chunks_per_group + c] from the mask (128 words per chunk of 4096 slots)
+__global__ __launch_bounds__(256) void count_chunks_mask_kernel(const uint32_t* __restrict__ mask, uint64_t mask_words,
+                                                                uint32_t chunks_per_group, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t g = blockIdx.x / chunks_per_group, c = blockIdx.x - g * chunks_per_group;
+    const uint64_t w0 = (uint64_t)c * (CHUNK / 32);
+    uint32_t cnt = 0;
+    if (threadIdx.x < CHUNK / 32 && w0 + threadIdx.x < mask_words) cnt = (uint32_t)__popc(mask[(size_t)g * mask_words + w0 + threadIdx.x]);
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+template <int SIGMA>
+__global__ __launch_bounds__(256) void write_chunks_c_kernel(CompTable ct, uint64_t table_size, uint32_t chunks_per_group, int k,
+                                                             const uint64_t* __restrict__ offsets,
+                                                             uint32_t* __restrict__ keys, float* __restrict__ scores)
+{
+    __shared__ uint32_t wcnt[4];
+    const uint32_t g = blockIdx.x / chunks_per_group, c = blockIdx.x - g * chunks_per_group;
+    const uint64_t s0 = (uint64_t)c * CHUNK;
+    const uint32_t n = (uint32_t)min((uint64_t)CHUNK, table_size - s0);
+    uint64_t out = offsets[blockIdx.x];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t v = 0;
+        if (i < n) v = ct.slot(g, s0 + i0 + wave * 64, lane);
+        const uint64_t m = __ballot(v != 0u);
+        if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) { const uint32_t x = wcnt[q]; total += x; if (q < wave) before += x; }
+        if (v != 0u) {
+            const uint64_t pos = out + before + mbcnt(m);
+            keys[pos] = pack_code<SIGMA>((uint32_t)(s0 + i), k);
+            scores[pos] = __uint_as_float(dec_score_bits(v));
+        }
+        out += total;
+        __syncthreads();
+    }
+}
 
 // ---- positions variant: 64-bit table (score code << 32 | ~sequence) -> keys, scores, positions -----
 __global__ __launch_bounds__(256) void count_chunks64_kernel(const unsigned long long* __restrict__ table, uint64_t table_size,

@@ -13,6 +13,7 @@
 // Everything is a coalesced sweep of the dense tables: no sort, no global atomics.
 #pragma once
 #include "dcla_device.hpp"
+#include "comp_table.hpp"
 
 namespace ipkgpu {
 
@@ -126,6 +127,51 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
             const uint32_t gl = i >> 6, xl = i & 63u;
             uint32_t v = 0;
             if (g0 + gl < G && x0 + xl < T) v = table[(size_t)(g0 + gl) * T + x0 + xl];
+            tile[gl][xl] = v;
+        }
+        __syncthreads();
+        const uint32_t br = (g0 + lane < G) ? branch_of_group[g0 + lane] : 0u;
+        for (uint32_t xl = wave; xl < 64; xl += 4) {
+            const uint32_t v = tile[lane][xl];
+            const uint64_t m = __ballot(v != 0u);
+            if (m == 0) continue;
+            const uint64_t base = run[xl];
+            if (v != 0u) entries[base + mbcnt(m)] = make_uint2(br, dec_score_bits(v));
+            if (lane == 0) run[xl] = base + (uint64_t)__popcll(m);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint64_t x = x0 + threadIdx.x;
+        if (x < T) cursor[(x % P) * slots + x / P] = run[threadIdx.x];
+    }
+}
+
+// km_write_kernel reading the compressed form.  Workgroup w takes key block (w % 8) * ceil(blocks / 8) + w / 8:
+// workgroups are dealt round-robin to the 8 XCDs, so each XCD walks one contiguous range of key blocks and the mask /
+// rank lines (eight / sixteen blocks per 64-byte line) are shared in its L2.
+__global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t T, uint32_t G,
+                                                         const uint32_t* __restrict__ branch_of_group, uint32_t P,
+                                                         uint64_t slots, uint64_t* __restrict__ cursor,
+                                                         uint2* __restrict__ entries)
+{
+    __shared__ uint32_t tile[64][65];
+    __shared__ uint64_t run[64];
+    const uint64_t nblocks = (T + 63) / 64, per_xcd = (nblocks + 7) / 8;
+    const uint64_t kb = (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || kb >= nblocks) return;
+    const uint64_t x0 = kb * 64;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    if (threadIdx.x < 64) {
+        const uint64_t x = x0 + threadIdx.x;
+        run[threadIdx.x] = (x < T) ? cursor[(x % P) * slots + x / P] : 0;
+    }
+    for (uint32_t g0 = 0; g0 < G; g0 += 64) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 4096; i += 256) {
+            const uint32_t gl = i >> 6, xl = i & 63u;
+            uint32_t v = 0;
+            if (g0 + gl < G && x0 + xl < T) v = ct.slot(g0 + gl, x0, xl);
             tile[gl][xl] = v;
         }
         __syncthreads();

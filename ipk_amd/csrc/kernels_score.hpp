@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void chunk_scatter_kernel(const unsigned long 
     list[off[gb] + atomicAdd(&cur[gb], 1u)] = make_uint2(i, (uint32_t)d);      // (chunk id, pair count)
 }
 
-// Occupancy bits of a finished LDS table slice (slots key0 .. key0 + nslots of one group; key0 a multiple of 32):
+// Occupancy bits of a finished LDS table slice (slots key0 .. key0 + nslots of one group; key0 a multiple of 64):
 // bit x % 32 of word x / 32 says table[x] != 0.  km_count sums these bits instead of re-reading the dense tables.
 __device__ __forceinline__ void store_slice_mask(const uint32_t* tab, uint32_t nslots, uint32_t* mask_words, uint32_t nthreads)
 {
@@ -704,9 +704,9 @@ __device__ __forceinline__ void store_slice_mask(const uint32_t* tab, uint32_t n
     for (uint32_t c = wave * 64; c < nslots; c += nwv * 64) {
         const uint32_t v = (c + lane < nslots) ? tab[c + lane] : 0u;
         const uint64_t m = __ballot(v != 0u);
-        if (lane == 0) {
+        if (lane == 0) {                       // rows are padded to whole 64-slot blocks (mask_words = 2 * ceil(T / 64))
             mask_words[c >> 5] = (uint32_t)m;
-            if (c + 32 < nslots) mask_words[(c >> 5) + 1] = (uint32_t)(m >> 32);
+            mask_words[(c >> 5) + 1] = (uint32_t)(m >> 32);
         }
     }
 }
@@ -1063,10 +1063,18 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_xp_kernel(XpParams
 
 // xp pass 3: one workgroup per (group, bucket); its pairs are ONE contiguous range of the pool
 // (segments of a (group, bucket) are adjacent in the scan order).
-template <uint32_t TBL, int NT>
-__global__ __launch_bounds__(NT) void reduce_ranges_kernel(const uint2* __restrict__ pool, const uint64_t* __restrict__ off,
+//
+// COMPRESS: for sparse tables (AA k=6: 28 % of 64 M slots per group) the dense slice is NOT written.  The group's
+// table is kept as  occupancy bits (mask)  +  the non-empty slots' score codes in slot order, written in place over
+// the head of the (group, bucket) pool range just consumed (unique slots <= pairs)  +  per 64-slot block the number
+// of non-empty slots before it in the slice (rank).  Slot x of group g then sits at
+//   values(g, b)[rank[g][x / 64] + popcount(mask64[g][x / 64] & below(x % 64))],  b = x / TBL,
+// values(g, b) = (u32*)(pool + off[(g * NB + b) * S]).  Consumers: km_write_c_kernel, write_chunks_c_kernel.
+template <uint32_t TBL, int NT, bool COMPRESS>
+__global__ __launch_bounds__(NT) void reduce_ranges_kernel(uint2* __restrict__ pool, const uint64_t* __restrict__ off,
                                                           uint32_t S, uint32_t NB, uint64_t T, uint32_t* __restrict__ table,
-                                                          uint32_t* __restrict__ mask, uint64_t mask_words)
+                                                          uint32_t* __restrict__ mask, uint64_t mask_words,
+                                                          uint32_t* __restrict__ rank, uint32_t* __restrict__ ucnt)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
@@ -1096,13 +1104,55 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(const uint2* __restri
             if (ci + (uint64_t)j * NT < r1) atomicMax(&tab[cur[j].x - k0], enc_score_bits(cur[j].y));
     }
     __syncthreads();
-    uint32_t* dst = table + (size_t)g * T + key0;
-    if ((nslots & 3u) == 0 && ((((size_t)g * T + key0) & 3u) == 0)) {
-        for (uint32_t z = threadIdx.x; z < nslots / 4; z += NT) reinterpret_cast<uint4*>(dst)[z] = reinterpret_cast<uint4*>(tab)[z];
+    if constexpr (!COMPRESS) {
+        uint32_t* dst = table + (size_t)g * T + key0;
+        if ((nslots & 3u) == 0 && ((((size_t)g * T + key0) & 3u) == 0)) {
+            for (uint32_t z = threadIdx.x; z < nslots / 4; z += NT) reinterpret_cast<uint4*>(dst)[z] = reinterpret_cast<uint4*>(tab)[z];
+        } else {
+            for (uint32_t z = threadIdx.x; z < nslots; z += NT) dst[z] = tab[z];
+        }
+        if (mask) store_slice_mask(tab, nslots, mask + (size_t)g * mask_words + (key0 >> 5), NT);
     } else {
-        for (uint32_t z = threadIdx.x; z < nslots; z += NT) dst[z] = tab[z];
+        constexpr uint32_t NWV = NT / 64, MAXBLK = (TBL + 63) / 64;
+        uint32_t* bcnt = tab + TBL;                                   // [MAXBLK + 1] non-empty slots per 64-slot block
+        const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+        const uint32_t nblk = (nslots + 63) / 64;
+        uint32_t* mrow = mask + (size_t)g * mask_words + (key0 >> 5);
+        for (uint32_t blk = wave; blk < nblk; blk += NWV) {
+            const uint32_t z = blk * 64 + lane;
+            const uint32_t val = z < nslots ? tab[z] : 0u;
+            const uint64_t m = __ballot(val != 0u);
+            if (lane == 0) {
+                bcnt[blk] = (uint32_t)__popcll(m);
+                mrow[2 * blk] = (uint32_t)m; mrow[2 * blk + 1] = (uint32_t)(m >> 32);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                              // exclusive scan of the block counts
+            constexpr uint32_t PERL = (MAXBLK + 63) / 64;
+            uint32_t own[PERL], sum = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < PERL; ++j) { const uint32_t q = lane * PERL + j; own[j] = q < nblk ? bcnt[q] : 0u; sum += own[j]; }
+            uint32_t incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += y; }
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (uint32_t j = 0; j < PERL; ++j) { const uint32_t q = lane * PERL + j; if (q < nblk) bcnt[q] = run; run += own[j]; }
+            if (lane == 63) bcnt[MAXBLK] = incl;                      // non-empty slots of the slice
+        }
+        __syncthreads();
+        uint32_t* vals = reinterpret_cast<uint32_t*>(pool + r0);      // in place: every pair of the range has been consumed
+        uint32_t* rrow = rank + (size_t)g * (mask_words / 2) + (key0 >> 6);
+        for (uint32_t blk = wave; blk < nblk; blk += NWV) {
+            const uint32_t z = blk * 64 + lane;
+            const uint32_t val = z < nslots ? tab[z] : 0u;
+            const uint64_t m = __ballot(val != 0u);
+            const uint32_t base = bcnt[blk];
+            if (lane == 0) rrow[blk] = base;
+            if (val != 0u) vals[base + mbcnt(m)] = val;
+        }
+        if (threadIdx.x == 0) ucnt[gb] = bcnt[MAXBLK];
     }
-    if (mask) store_slice_mask(tab, nslots, mask + (size_t)g * mask_words + (key0 >> 5), NT);
 }
 
 }  // namespace ipkgpu

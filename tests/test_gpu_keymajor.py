@@ -44,7 +44,8 @@ def test_single_owner_db(engine, sigma, k, sites, alpha):
 
 
 @pytest.mark.parametrize("sigma,k,sites,alpha,variant", [(20, 6, 40, 0.06, 0), (4, 12, 1500, 0.05, 0), (4, 10, 120, 0.1, 1),
-                                                          (4, 10, 120, 0.1, 3), (20, 2, 50, 0.2, 0)])
+                                                          (4, 10, 120, 0.1, 3), (4, 10, 120, 0.1, 4), (4, 12, 300, 0.05, 4), (20, 2, 50, 0.2, 4),
+                                                          (20, 4, 30, 0.05, 4), (20, 2, 50, 0.2, 0)])
 def test_db_counts_follow_every_scoring_variant(engine, sigma, k, sites, alpha, variant):
     """The key-major counts come from the occupancy bits the LDS reduce leaves behind (stream / exact-partition
     variants) -- kept current by the big-list kernel's atomics, which the first two cases exercise (42 of 105 and 4 of

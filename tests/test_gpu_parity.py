@@ -195,13 +195,16 @@ def test_v1_variant_still_matches(engine):
 
 @pytest.mark.parametrize("sigma,k,sites,alpha", [(4, 5, 60, 0.3), (4, 8, 120, 0.2), (4, 10, 300, 0.1), (4, 10, 200, 1.0), (4, 12, 80, 0.1),
                                                  (20, 2, 40, 0.2), (20, 4, 40, 0.05), (20, 5, 30, 0.03), (20, 6, 40, 0.03)])
-def test_exact_partition_variant(engine, sigma, k, sites, alpha):
-    """variant=3: count -> scan -> write -> LDS reduce (the default for AA k=6) on every (sigma, k) it exists for."""
+@pytest.mark.parametrize("variant", [3, 4])
+def test_exact_partition_variant(engine, sigma, k, sites, alpha, variant):
+    """count -> scan -> write -> LDS reduce (the default for AA k=6) on every (sigma, k) it exists for; variant 3 ends in
+    dense tables, variant 4 in the compressed form (occupancy bits + rank + values in place in the pool)."""
     mats = synth_matrices(5, sites, sigma, alpha, 300 + 10 * sigma + k)
     groups = np.array([3, 8, 3, 8, 1], dtype=np.uint32)
-    engine.set_option("variant", 3)
+    engine.set_option("variant", variant)
     try:
         check_against_oracle(engine, mats, groups, k, co.log_threshold(1.5, sigma, k))
+        check_against_oracle(engine, mats[:2], [6, 2], k, co.log_threshold(1.5, sigma, k), device=True)
     finally:
         engine.set_option("variant", 0)
 
