@@ -521,7 +521,7 @@ int launch_xp_reduce(ipkgpu_ctx* ctx, uint32_t n_gb, uint32_t S, uint64_t T, con
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
         static_assert(!COMPRESS || NB == 1 || TBL % 64 == 0, "a 64-slot block must not straddle two buckets");
         constexpr int NT = TBL <= 16384 ? 512 : 1024;
-        constexpr size_t lds = (size_t)TBL * 4 + (COMPRESS ? ((TBL + 63) / 64 + 1) * 4 : 0);
+        constexpr size_t lds = (size_t)TBL * 4 + (COMPRESS ? (NT / 64 + 1) * 4 : 0);
         auto kern = reduce_ranges_kernel<TBL, NT, COMPRESS>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -872,9 +872,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const uint32_t XNB = xp_buckets(pl.sigma, pl.k);
     // variant 0 = default: stream where its per-wave chunk state fits (all DNA k, AA k <= 5), exact partition for
     // AA k=6; 1 = global atomics, 2 = stream (diagnostic flags honoured), 3 = exact partition wherever it exists
-    //                 4 = exact partition with the compressed table form (the default for AA k=6: 28 % occupancy)
+    //                 4 = exact partition ending in the compressed table form (no dense tables: 64 GB less at cfg4, 40 %
+    //                     fewer bytes moved, but its reduce pass is latency-bound at one workgroup per CU: 93.5 vs 91.3 ms)
     const bool use_xp = XNB != 0 && (ctx->opt_variant == 3 || ctx->opt_variant == 4 || (ctx->opt_variant == 0 && NBK == 0));
-    const bool xp_compress = use_xp && ctx->opt_variant != 3;
+    const bool xp_compress = use_xp && ctx->opt_variant == 4;
     const bool use_stream = !use_xp && NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
     const uint32_t SNW = stream_waves(pl.sigma, pl.k), STW = stream_tile(pl.sigma, pl.k);
     const uint32_t s_tiles_per_mat = (pl.nwin + STW - 1) / STW;

@@ -157,10 +157,13 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
 {
     __shared__ uint32_t tile[64][65];
     __shared__ uint64_t run[64];
+    __shared__ uint64_t row_mask[64];
+    __shared__ const uint32_t* row_vals[64];
     const uint64_t nblocks = (T + 63) / 64, per_xcd = (nblocks + 7) / 8;
     const uint64_t kb = (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || kb >= nblocks) return;
     const uint64_t x0 = kb * 64;
+    const uint32_t b = (uint32_t)(x0 / ct.TBL);
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     if (threadIdx.x < 64) {
         const uint64_t x = x0 + threadIdx.x;
@@ -168,10 +171,25 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
     }
     for (uint32_t g0 = 0; g0 < G; g0 += 64) {
         __syncthreads();
+        // one thread per group row: the block's occupancy bits and where its values start (three independent loads)
+        if (threadIdx.x < 64) {
+            const uint32_t g = g0 + threadIdx.x;
+            uint64_t m = 0;
+            const uint32_t* vp = nullptr;
+            if (g < G) {
+                const uint32_t* mw = ct.mask + (size_t)g * ct.mask_words + 2 * kb;
+                m = (uint64_t)mw[0] | ((uint64_t)mw[1] << 32);
+                vp = reinterpret_cast<const uint32_t*>(ct.pool + ct.off[((size_t)g * ct.NB + b) * ct.stride]) +
+                     ct.rank[(size_t)g * (ct.mask_words / 2) + kb];
+            }
+            row_mask[threadIdx.x] = m; row_vals[threadIdx.x] = vp;
+        }
+        __syncthreads();
         for (uint32_t i = threadIdx.x; i < 4096; i += 256) {
             const uint32_t gl = i >> 6, xl = i & 63u;
+            const uint64_t m = row_mask[gl];
             uint32_t v = 0;
-            if (g0 + gl < G && x0 + xl < T) v = ct.slot(g0 + gl, x0, xl);
+            if ((m >> xl) & 1ull) v = row_vals[gl][(uint32_t)__popcll(m & ((1ull << xl) - 1ull))];
             tile[gl][xl] = v;
         }
         __syncthreads();

@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(uint2* __restrict__ p
     const uint64_t key0 = (uint64_t)b * TBL;
     const uint32_t nslots = (uint32_t)min((uint64_t)TBL, T - key0);
     const uint64_t r0 = off[(size_t)gb * S], r1 = off[(size_t)gb * S + S];     // S = slots per (group, bucket) in the scan
-    constexpr int PER = 4;
+    constexpr int PER = 8;
     uint2 v[PER];
     uint64_t i = r0 + threadIdx.x;
 #pragma unroll
@@ -1113,45 +1113,40 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(uint2* __restrict__ p
         }
         if (mask) store_slice_mask(tab, nslots, mask + (size_t)g * mask_words + (key0 >> 5), NT);
     } else {
-        constexpr uint32_t NWV = NT / 64, MAXBLK = (TBL + 63) / 64;
-        uint32_t* bcnt = tab + TBL;                                   // [MAXBLK + 1] non-empty slots per 64-slot block
+        // every wave owns a contiguous range of 64-slot blocks: totals per wave, then each wave runs its own offsets
+        constexpr uint32_t NWV = NT / 64, MAXBLK = (TBL + 63) / 64, BPW = (MAXBLK + NWV - 1) / NWV;
+        uint32_t* wtot = tab + TBL;                                   // [NWV + 1]
         const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
         const uint32_t nblk = (nslots + 63) / 64;
-        uint32_t* mrow = mask + (size_t)g * mask_words + (key0 >> 5);
-        for (uint32_t blk = wave; blk < nblk; blk += NWV) {
-            const uint32_t z = blk * 64 + lane;
-            const uint32_t val = z < nslots ? tab[z] : 0u;
-            const uint64_t m = __ballot(val != 0u);
-            if (lane == 0) {
-                bcnt[blk] = (uint32_t)__popcll(m);
-                mrow[2 * blk] = (uint32_t)m; mrow[2 * blk + 1] = (uint32_t)(m >> 32);
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {                                              // exclusive scan of the block counts
-            constexpr uint32_t PERL = (MAXBLK + 63) / 64;
-            uint32_t own[PERL], sum = 0;
+        const uint32_t b_lo = min(nblk, wave * BPW), b_hi = min(nblk, b_lo + BPW);
+        // the wave's blocks in registers (all LDS reads in flight together), then counting and writing run on registers
+        uint32_t vr[BPW];
+        uint32_t mine = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < PERL; ++j) { const uint32_t q = lane * PERL + j; own[j] = q < nblk ? bcnt[q] : 0u; sum += own[j]; }
-            uint32_t incl = sum;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += y; }
-            uint32_t run = incl - sum;
-#pragma unroll
-            for (uint32_t j = 0; j < PERL; ++j) { const uint32_t q = lane * PERL + j; if (q < nblk) bcnt[q] = run; run += own[j]; }
-            if (lane == 63) bcnt[MAXBLK] = incl;                      // non-empty slots of the slice
+        for (uint32_t j = 0; j < BPW; ++j) {
+            const uint32_t z = (b_lo + j) * 64 + lane;
+            vr[j] = (b_lo + j < b_hi && z < nslots) ? tab[z] : 0u;
         }
+#pragma unroll
+        for (uint32_t j = 0; j < BPW; ++j) mine += (uint32_t)__popcll(__ballot(vr[j] != 0u));
+        if (lane == 0) wtot[wave] = mine;
         __syncthreads();
+        uint32_t base = 0, all = 0;
+        for (uint32_t w = 0; w < NWV; ++w) { const uint32_t t = wtot[w]; if (w < wave) base += t; all += t; }
         uint32_t* vals = reinterpret_cast<uint32_t*>(pool + r0);      // in place: every pair of the range has been consumed
+        uint32_t* mrow = mask + (size_t)g * mask_words + (key0 >> 5);
         uint32_t* rrow = rank + (size_t)g * (mask_words / 2) + (key0 >> 6);
-        for (uint32_t blk = wave; blk < nblk; blk += NWV) {
-            const uint32_t z = blk * 64 + lane;
-            const uint32_t val = z < nslots ? tab[z] : 0u;
-            const uint64_t m = __ballot(val != 0u);
-            const uint32_t base = bcnt[blk];
-            if (lane == 0) rrow[blk] = base;
-            if (val != 0u) vals[base + mbcnt(m)] = val;
+#pragma unroll
+        for (uint32_t j = 0; j < BPW; ++j) {
+            const uint32_t blk = b_lo + j;
+            const uint64_t m = __ballot(vr[j] != 0u);
+            if (blk < b_hi) {
+                if (lane == 0) { rrow[blk] = base; mrow[2 * blk] = (uint32_t)m; mrow[2 * blk + 1] = (uint32_t)(m >> 32); }
+                if (vr[j] != 0u) vals[base + mbcnt(m)] = vr[j];
+            }
+            base += (uint32_t)__popcll(m);
         }
-        if (threadIdx.x == 0) ucnt[gb] = bcnt[MAXBLK];
+        if (threadIdx.x == 0) ucnt[gb] = all;
     }
 }
 
