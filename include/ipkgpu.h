@@ -66,8 +66,9 @@ const char* ipkgpu_last_error(const ipkgpu_ctx* ctx);
 /* Options: "workspace_bytes" (max bytes of per-group score tables resident at once; groups are
  * processed in batches that fit); "variant" (0 = auto: LDS max-reduce fed by the chunked pair pool, or by
  * the exact-partition passes for AA k=6; 1 = global-atomic max-reduce; 2 = force the chunked pool;
- * 3 = force the exact partition; 4 = exact partition ending in compressed tables (occupancy bits + rank +
- * scores instead of dense per-group tables)); "debug_flags" / "debug_pool_chunks" (diagnostics and tests only).
+ * 3 = force the exact partition with dense tables; 4 = exact partition ending in compressed tables (occupancy
+ * bits + rank + scores instead of dense per-group tables; what auto picks for AA k=6)); "debug_flags" /
+ * "debug_pool_chunks" (diagnostics and tests only).
  * Every variant yields identical results.  Returns IPKGPU_ERR_INVALID for unknown names. */
 int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value);
 

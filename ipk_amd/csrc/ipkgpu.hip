@@ -455,10 +455,10 @@ template <int SIGMA, int K> uint32_t stream_nb() {
 }
 
 // ---- exact-partition variant (count -> scan -> write -> reduce), kernels_score.hpp ---------------------
-constexpr int XP_NW = 10, XP_TW = 128;
+constexpr int XP_NW = 11, XP_TW = 128;   // 11 waves: what fits 160 KB of LDS at AA k=6 (12 with 64-window tiles measured equal)
 template <int SIGMA, int K> constexpr uint32_t xp_tbl()
 {
-    if (SIGMA == 20 && K == 6) return 32000u;                           // 2000 buckets per group
+    if (SIGMA == 20 && K == 6) return 16000u;                           // 4000 buckets per group; 64 KB reduce tables: two workgroups per CU
     return stream_tbl<SIGMA, K>();
 }
 template <int SIGMA, int K> uint32_t xp_nb() {
@@ -471,7 +471,7 @@ template <int SIGMA, int K> size_t xp_lds(bool write) {
     else {
         constexpr int CAP = fast_cap<SIGMA, K>();
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
-        return TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * (write ? 8 : 4);
+        return TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * 4;
     }
 }
 template <int SIGMA, int K, bool WRITE>
@@ -482,7 +482,7 @@ int launch_xp(ipkgpu_ctx* ctx, const XpParams& xp, uint32_t n_wg)
     else {
         constexpr int CAP = fast_cap<SIGMA, K>();
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
-        constexpr size_t lds = TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * (WRITE ? 8 : 4);
+        constexpr size_t lds = TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * 4;
         static_assert(lds <= 160 * 1024, "exact-partition LDS budget");
         static_assert((TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8) % 8 == 0, "cursor alignment");
         auto kern = score_xp_kernel<SIGMA, K, CAP, XP_TW, XP_NW, TBL, WRITE>;
@@ -520,7 +520,7 @@ int launch_xp_reduce(ipkgpu_ctx* ctx, uint32_t n_gb, uint32_t S, uint64_t T, con
     else {
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
         static_assert(!COMPRESS || NB == 1 || TBL % 64 == 0, "a 64-slot block must not straddle two buckets");
-        constexpr int NT = TBL <= 16384 ? 512 : 1024;
+        constexpr int NT = TBL <= 16384 ? 512 : 1024;       // (1024 threads on 16000-slot tables measured slower: 24.3 vs 18.5 ms)
         constexpr size_t lds = (size_t)TBL * 4 + (COMPRESS ? (NT / 64 + 1) * 4 : 0);
         auto kern = reduce_ranges_kernel<TBL, NT, COMPRESS>;
         if (lds > 64 * 1024)
@@ -872,10 +872,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const uint32_t XNB = xp_buckets(pl.sigma, pl.k);
     // variant 0 = default: stream where its per-wave chunk state fits (all DNA k, AA k <= 5), exact partition for
     // AA k=6; 1 = global atomics, 2 = stream (diagnostic flags honoured), 3 = exact partition wherever it exists
-    //                 4 = exact partition ending in the compressed table form (no dense tables: 64 GB less at cfg4, 40 %
-    //                     fewer bytes moved, but its reduce pass is latency-bound at one workgroup per CU: 93.5 vs 91.3 ms)
+    //                 4 = exact partition ending in the compressed table form (the default for AA k=6: no dense tables --
+    //                     64 GB less at cfg4, 40 % fewer bytes moved; 90.5 vs 92.0 ms through dense tables)
     const bool use_xp = XNB != 0 && (ctx->opt_variant == 3 || ctx->opt_variant == 4 || (ctx->opt_variant == 0 && NBK == 0));
-    const bool xp_compress = use_xp && ctx->opt_variant == 4;
+    const bool xp_compress = use_xp && ctx->opt_variant != 3;
     const bool use_stream = !use_xp && NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
     const uint32_t SNW = stream_waves(pl.sigma, pl.k), STW = stream_tile(pl.sigma, pl.k);
     const uint32_t s_tiles_per_mat = (pl.nwin + STW - 1) / STW;

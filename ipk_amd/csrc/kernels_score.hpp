@@ -824,7 +824,7 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
     constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
     static_assert(TBL % mulR == 0, "a row of the final join must stay inside one bucket");
     constexpr uint32_t RPB = TBL / mulR;                    // rows (L codes) per bucket
-    using Cursor = typename std::conditional<WRITE, unsigned long long, uint32_t>::type;
+    using Cursor = uint32_t;                                // count: pairs of the bucket; write: pairs placed so far
     float* cols = reinterpret_cast<float*>(smem);
     float* best = cols + TG::COLS_F;
     uint2* scratch_all = reinterpret_cast<uint2*>(smem + TG::HEAD_BYTES);
@@ -837,10 +837,7 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
     const uint32_t t_lo = (uint32_t)(((uint64_t)total_tiles * seg) / p.S);
     const uint32_t t_hi = (uint32_t)(((uint64_t)total_tiles * (seg + 1)) / p.S);
     const size_t ub = (size_t)g * NB * xp.stride + seg;     // this unit's slot of bucket b: ub + b * stride
-    for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) {
-        if constexpr (WRITE) cur[b] = xp.off[ub + (size_t)b * xp.stride];
-        else cur[b] = 0;
-    }                                                       // (the first tile's barriers order this before any use)
+    for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) cur[b] = 0;    // (the first tile's barriers order this before any use)
 
     uint2* scratch = scratch_all + (size_t)wave * WS;
     unsigned long long emitted = 0;                         // per lane
@@ -950,8 +947,8 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
                     emitted += cnt;
                     if (cnt) atomicAdd(&cur[bk], cnt);
                 } else {
-                    unsigned long long pos = 0;
-                    if (cnt) pos = atomicAdd(&cur[bk], (unsigned long long)cnt);
+                    unsigned long long pos = 0;            // the unit's range of the bucket starts at its scan offset
+                    if (cnt) pos = xp.off[ub + (size_t)bk * xp.stride] + atomicAdd(&cur[bk], cnt);
                     const uint32_t rows = min(64u, nL - ib);
                     for (uint32_t r = 0; r < rows; ++r) {
                         const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)r);
