@@ -465,7 +465,7 @@ template <int SIGMA, int K> uint32_t xp_nb() {
     constexpr uint32_t TBL = xp_tbl<SIGMA, K>();
     if constexpr (TBL == 0) return 0; else return (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
 }
-template <int SIGMA, int K> size_t xp_lds(bool write) {
+template <int SIGMA, int K> size_t xp_lds() {
     constexpr uint32_t TBL = xp_tbl<SIGMA, K>();
     if constexpr (TBL == 0) return 0;
     else {
@@ -621,9 +621,9 @@ uint32_t xp_buckets(uint32_t sigma, uint32_t k)
 #undef M_XNB
     return 0;
 }
-size_t xp_lds_bytes(uint32_t sigma, uint32_t k, bool write)
+size_t xp_lds_bytes(uint32_t sigma, uint32_t k)
 {
-#define M_XLDS(S_, K_) return xp_lds<S_, K_>(write)
+#define M_XLDS(S_, K_) return xp_lds<S_, K_>()
     IPK_DISPATCH(sigma, k, M_XLDS);
 #undef M_XLDS
     return 0;
@@ -760,7 +760,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
 {
     (void)nb;
     const uint32_t tiles_per_mat = (pl.nwin + XP_TW - 1) / XP_TW;
-    const size_t lds_bytes = xp_lds_bytes(pl.sigma, pl.k, true);
+    const size_t lds_bytes = xp_lds_bytes(pl.sigma, pl.k);
     const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / XP_NW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
     const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
     // four rounds of resident workgroups balance the tail; a unit costs only its NB counters
