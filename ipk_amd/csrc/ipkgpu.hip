@@ -1511,8 +1511,11 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         Batch& b = batches.back();
         HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.counts, n_slots_all * 4));
         HIP_TRY(ctx, hipMemsetAsync(b.counts, 0, n_slots_all * 4, ctx->stream));
-        if (ctx->mask_valid)
-            hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
+        if (ctx->mask_valid && (T + 31) / 32 >= (uint64_t)ctx->num_cu * 1024)      // a thread per mask word fills the chip
+            hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)(((T + 31) / 32 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->mask.as<uint32_t>(), ctx->mask_words, T, gb, P, slots, b.counts);
+        else if (ctx->mask_valid)
+            hipLaunchKernelGGL(km_count_mask_key_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
                                ctx->mask.as<uint32_t>(), ctx->mask_words, T, gb, P, slots, b.counts);
         else
             hipLaunchKernelGGL(km_count_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,

@@ -37,9 +37,46 @@ __global__ __launch_bounds__(256) void km_count_kernel(const uint32_t* __restric
 }
 
 // The same counts from the occupancy bits the LDS reduce passes leave behind (kernels_score.hpp,
-// store_slice_mask): 1/32 of the bytes of the dense tables.
+// store_slice_mask): 1/32 of the bytes of the dense tables.  One thread per mask word (32 keys); the words of
+// successive groups are added into eight bit planes (a ripple-carry add of a 1-bit number: 16 logic operations for
+// 32 keys), emptied into the 32 per-key totals every 255 groups.
 __global__ __launch_bounds__(256) void km_count_mask_kernel(const uint32_t* __restrict__ mask, uint64_t W, uint64_t T,
                                                             uint32_t G, uint32_t P, uint64_t slots, uint32_t* __restrict__ counts)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w * 32 >= T) return;
+    uint32_t plane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t total[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) total[b] = 0;
+    const uint32_t* m = mask + w;
+    for (uint32_t g0 = 0; g0 < G; g0 += 255) {
+        const uint32_t g1 = min(G, g0 + 255u);
+        for (uint32_t g = g0; g < g1; ++g) {
+            uint32_t carry = m[(size_t)g * W];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { const uint32_t t = plane[p] & carry; plane[p] ^= carry; carry = t; }
+        }
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) c |= ((plane[p] >> b) & 1u) << p;
+            total[b] += c;
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) plane[p] = 0;
+    }
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+        const uint64_t x = w * 32 + b;
+        if (x < T) counts[(x % P) * slots + x / P] = total[b];
+    }
+}
+
+// One thread per key: for key spaces too small to fill the chip with one thread per mask word (DNA k <= 11).
+__global__ __launch_bounds__(256) void km_count_mask_key_kernel(const uint32_t* __restrict__ mask, uint64_t W, uint64_t T,
+                                                                uint32_t G, uint32_t P, uint64_t slots, uint32_t* __restrict__ counts)
 {
     const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (x >= T) return;
