@@ -205,6 +205,19 @@ def main():
                                    "sample": f"first {n_cpu} of {ng} branch groups of the same workload "
                                              f"({e_cpu} scored k-mers, {tc:.1f} s), oracle/ipk_oracle.c -O3, 1 thread "
                                              f"(the reference build loop is single-threaded)"}
+            # the generous baseline: the same sample with the groups dealt to every host core this process may use
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            if cores > 1 and n_cpu >= 2:
+                from concurrent.futures import ThreadPoolExecutor
+                nt = min(cores, n_cpu, int(os.environ.get("IPK_BENCH_CPU_THREADS", "16")))      # a one-GPU box has a 16-core share
+                cuts = [n_cpu * i // nt for i in range(nt + 1)]
+                tm = time.perf_counter()
+                with ThreadPoolExecutor(nt) as ex:              # ctypes releases the GIL inside the C oracle
+                    parts = list(ex.map(lambda i: co.explore_many(sample[cuts[i] * mpg:cuts[i + 1] * mpg], mpg, k, eps), range(nt)))
+                tm = time.perf_counter() - tm
+                assert sum(p_[0] for p_ in parts) == e_cpu
+                out["cpu_baseline"]["all_cores"] = {"value": e_cpu / tm, "unit": "phylo-k-mers/s", "cores": nt,
+                                                    "sample": f"the same {n_cpu} groups, one thread per group range, {tm:.1f} s"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -27,5 +27,7 @@ def test_bench_json_contract():
     assert "traffic" in r and r["achieved"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    if "all_cores" in c:                       # present when the process may use more than one core
+        assert c["all_cores"]["cores"] >= 2 and c["all_cores"]["value"] > 0
     assert d["sample_check"]["scored_equal"] and d["sample_check"]["entries_equal"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
