@@ -368,14 +368,12 @@ template <int SIGMA, int K> constexpr uint32_t stream_tbl()
     if (SIGMA == 4) return T <= 16384 ? (uint32_t)T : (K <= 10 ? 16384u : 32768u);
     if (K <= 3) return (uint32_t)T;                                     // 400, 8000
     if (K <= 5) return 32000u;                                          // 20^4 = 5 x 32000, 20^5 = 100 x 32000
-    return 0;   // AA k=6: 2000 buckets per group.  Tried with two waves per workgroup (16 KB of chunk state per wave):
-                // pass 1 143 ms + reduce 19 ms vs 132 ms for the global-atomic variant -- occupancy-starved, so atomics stay
+    return 0;   // AA k=6: 2000 buckets per group = 16 KB of open-chunk state per WAVE; measured with two waves per workgroup:
+                // pass 1 143 ms (occupancy-starved).  That key space takes the exact-partition variant instead (xp_tbl).
 }
 
-
-// AA k=6 keeps 2000 open chunks per wave (16 KB of LDS state): two waves per workgroup, 64-window tiles
-template <int SIGMA, int K> constexpr int stream_nw() { return (SIGMA == 20 && K == 6) ? 2 : NW; }
-template <int SIGMA, int K> constexpr int stream_tw() { return (SIGMA == 20 && K == 6) ? 64 : TW; }
+template <int SIGMA, int K> constexpr int stream_nw() { return NW; }
+template <int SIGMA, int K> constexpr int stream_tw() { return TW; }
 
 template <int SIGMA, int K>
 int launch_stream_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
@@ -795,8 +793,6 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     const int ev_a2 = sw.mark();
     RC_TRY(dispatch_xp_overflow(ctx, pl.sigma, pl.k, xp, false));          // reads the queue length on the device
     RC_TRY(scan_u32(ctx, xp.cnt, n_units, ctx->gboff.as<uint64_t>()));
-    const int ev_b = sw.mark();
-    (void)ev_b;
     uint64_t total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->gboff.as<uint64_t>() + n_units, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
