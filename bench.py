@@ -152,6 +152,8 @@ def main():
             main_kernel = "score_xp_kernel (count + write launches together)"     # exact-partition variant scores twice
         avg_score_ms = score_ms / max(launches, 1)
         avg_main_ms = acc["main"] / max(launches, 1)          # the dominant kernel alone (HIP events on its stream)
+        # a step is one launch per batch or, with several ranks, per piece of the rank's groups: bytes per LAUNCH
+        b_alg = b_alg * args.steps / max(launches, 1)
         achieved = b_alg / (avg_main_ms * 1e-3) / 1e9 if avg_main_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes

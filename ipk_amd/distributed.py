@@ -71,36 +71,53 @@ def _a2a(dist, out, inp, out_splits=None, in_splits=None, async_op=False):
     return w if async_op else _Done()
 
 
-def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=1, rank=0, overlap=True):
+def _piece_cuts(mat_group, order, n):
+    """Matrix cut points of n contiguous ranges of the groups (first-seen order), or None if the matrices of the
+    ranges interleave (the pieces are scored from slices of the matrix array)."""
+    piece_of = {g: min(n - 1, i * n // len(order)) for i, g in enumerate(order)}
+    pid = np.array([piece_of[g] for g in mat_group.tolist()])
+    if np.any(np.diff(pid) < 0):
+        return None
+    return [int(np.searchsorted(pid, j, side="left")) for j in range(n)] + [len(pid)]
+
+
+def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=1, rank=0, overlap=True, pieces=None):
     """Scores this rank's groups and returns (this rank's database shard, parts) -- the state
     `_phylo_kmer_db` has after explore_kmers (db_builder.cpp:576-627), sharded by k-mer owner.
 
-    With several ranks the groups are scored in two halves so that the all-to-all of the first half's
-    blocks (RCCL, its own stream) runs while the second half is being scored; the merge then takes
-    2 x world sources in the order (rank 0 first half, rank 0 second half, rank 1 first half, ...),
-    which is global group order."""
+    With several ranks the groups are scored in `pieces` contiguous ranges (default 4, IPK_DIST_PIECES) so that the
+    all-to-all of one range's blocks (RCCL, its own stream) runs while the next range is being scored -- only the last
+    range's transfer is exposed; the merge then takes pieces x world sources in the order (rank 0 piece 0, rank 0
+    piece 1, ..., rank 1 piece 0, ...), which is global group order.  The ranks agree on the piece count (the smallest
+    any of them can do), so uneven shards cannot desynchronise the collectives."""
     if world == 1:
         parts = engine.score_groups_keymajor(logp, mat_group, k, log_eps, n_owners=1)
         return engine.db_from_parts(parts, sigma, k), parts
 
+    import os
     import torch
     mat_group = np.ascontiguousarray(mat_group, dtype=np.uint32)
     order = list(dict.fromkeys(mat_group.tolist()))                      # groups in first-seen order
-    first = set(order[:len(order) // 2])
-    in_a = np.array([g in first for g in mat_group.tolist()])
-    na = int(in_a.sum())
-    two_halves = (overlap and len(order) >= 2 and hasattr(logp, "data_ptr")
-                  and bool(np.all(in_a[:na])) and not bool(np.any(in_a[na:])))      # halves must not interleave
-    if not two_halves:
+    want = pieces if pieces is not None else int(os.environ.get("IPK_DIST_PIECES", "4"))
+    n = 1
+    if overlap and hasattr(logp, "data_ptr"):
+        n = max(1, min(want, len(order)))
+        while n > 1 and _piece_cuts(mat_group, order, n) is None:
+            n -= 1
+    on_gpu = dist.get_backend() != "gloo"
+    agreed = torch.tensor([n], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+    n = int(agreed.item())
+    if n <= 1:
         parts = engine.score_groups_keymajor(logp, mat_group, k, log_eps, n_owners=world)
         rc, re_, so = exchange_parts(parts.counts_tensor(), parts.entries_tensor(), parts.owner_offsets, dist, world)
         torch.cuda.current_stream().synchronize()
         return engine.merge_parts(sigma, k, rank, world, rc, re_, so), parts
-
+    cuts = _piece_cuts(mat_group, order, n)
     dev = logp.device
 
     def exchange(parts):
-        """Starts the transfer of one half's blocks; returns the receive buffers and the pending work."""
+        """Starts the transfer of one piece's blocks; returns the receive buffers and the pending work."""
         counts, entries = parts.counts_tensor(), parts.entries_tensor()
         send = _split_sizes(parts.owner_offsets, world)
         rs = torch.empty(world, dtype=torch.int64, device=dev)
@@ -112,26 +129,35 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
                  _a2a(dist, rentries, entries, recv, send, async_op=True)]
         return dict(recv=recv, rcounts=rcounts, rentries=rentries, works=works, keep=(counts, entries))
 
-    pa = engine.score_groups_keymajor(logp[:na], mat_group[:na], k, log_eps, n_owners=world)
-    xa = exchange(pa)                                                    # in flight while the second half is scored
-    pb = engine.score_groups_keymajor(logp[na:], mat_group[na:], k, log_eps, n_owners=world)
-    xb = exchange(pb)
-    for w in xa["works"] + xb["works"]:
-        w.wait()
+    scored, xs = [], []
+    for j in range(n):
+        pj = engine.score_groups_keymajor(logp[cuts[j]:cuts[j + 1]], mat_group[cuts[j]:cuts[j + 1]], k, log_eps, n_owners=world)
+        scored.append(pj)
+        xs.append(exchange(pj))                                          # in flight while the next piece is scored
+    for x in xs:
+        for w in x["works"]:
+            w.wait()
     torch.cuda.current_stream().synchronize()
-    # sources in global group order: (rank r, first half), (rank r, second half)
-    counts = torch.stack([xa["rcounts"], xb["rcounts"]], dim=1).reshape(2 * world, -1).contiguous()
-    # both receive buffers are addressed from the lower of the two base pointers (entries are 8 bytes)
-    pa_ptr, pb_ptr = xa["rentries"].data_ptr(), xb["rentries"].data_ptr()
-    base = min(pa_ptr, pb_ptr) if xa["rentries"].numel() and xb["rentries"].numel() else (pa_ptr or pb_ptr)
-    offa = np.concatenate([[0], np.cumsum(xa["recv"])[:-1]]) + (pa_ptr - base) // 8 if xa["rentries"].numel() else np.zeros(world)
-    offb = np.concatenate([[0], np.cumsum(xb["recv"])[:-1]]) + (pb_ptr - base) // 8 if xb["rentries"].numel() else np.zeros(world)
-    so = np.stack([offa, offb], axis=1).reshape(-1).astype(np.uint64)
+    # sources in global group order: (rank r, piece 0), (rank r, piece 1), ...
+    counts = torch.stack([x["rcounts"] for x in xs], dim=1).reshape(n * world, -1).contiguous()
+    # all receive buffers are addressed from the lowest base pointer among them (entries are 8 bytes)
+    ptrs = [x["rentries"].data_ptr() for x in xs if x["rentries"].numel()]
+    base = min(ptrs) if ptrs else xs[0]["rentries"].data_ptr()
+    offs = []
+    for x in xs:
+        if x["rentries"].numel():
+            offs.append(np.concatenate([[0], np.cumsum(x["recv"])[:-1]]) + (x["rentries"].data_ptr() - base) // 8)
+        else:
+            offs.append(np.zeros(world))
+    so = np.stack(offs, axis=1).reshape(-1).astype(np.uint64)
     torch.cuda.synchronize()
     db = engine.merge_parts(sigma, k, rank, world, counts, base, so)
-    pa.emitted += pb.emitted
-    pb.free()
-    return db, pa
+    for pj in scored[1:]:
+        scored[0].emitted += pj.emitted
+        for which in range(7):                                           # IPKGPU_T_* selectors
+            scored[0].extra_ms[which] = scored[0].extra_ms.get(which, 0.0) + pj.time_ms(which)
+        pj.free()
+    return db, scored[0]
 
 
 def write_db_file(path, sequence_type, tree_index, newick, kmer_size, omega, keys, key_offsets, branches, scores,

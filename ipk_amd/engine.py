@@ -351,6 +351,7 @@ class Parts:
         self.slots = int(lib.ipkgpu_parts_slots(handle))
         self.owner_offsets = np.ctypeslib.as_array(lib.ipkgpu_parts_owner_offsets(handle), shape=(self.n_owners + 1,)).copy()
         self.emitted = int(lib.ipkgpu_parts_emitted(handle))
+        self.extra_ms = {}        # timings of further pieces folded into this object (distributed.build_db_shard)
 
     @property
     def num_entries(self):
@@ -363,7 +364,7 @@ class Parts:
         return self._lib.ipkgpu_parts_entries_device(self._h)
 
     def time_ms(self, which):
-        return float(self._lib.ipkgpu_parts_time_ms(self._h, which))
+        return float(self._lib.ipkgpu_parts_time_ms(self._h, which)) + self.extra_ms.get(which, 0.0)
 
     def counts_tensor(self):
         """torch view [n_owners, slots] int32 of the device counts (keeps self alive)."""

@@ -167,7 +167,7 @@ def test_mif0_filter_values_and_order(engine, sigma, k, sites):
     db.free(); parts.free()
 
 
-def _rank_worker(rank, world, port, out_dir):
+def _rank_worker(rank, world, port, out_dir, n_groups=6):
     """One process per rank (both on GPU 0, gloo transport): the bench's N>1 path end to end."""
     import os
     import torch
@@ -178,7 +178,7 @@ def _rank_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        sigma, k, n_groups, mpg, sites = 4, 8, 6, 2, 120
+        sigma, k, mpg, sites = 4, 8, 2, 120
         mats = synth_matrices(n_groups * mpg, sites, sigma, 0.1, 4242)
         groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 50, mpg)
         g0, g1 = D.shard_range(n_groups, world, rank)
@@ -193,13 +193,16 @@ def _rank_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_build_with_exchange(tmp_path):
+@pytest.mark.parametrize("n_groups", [6, 3, 11])
+def test_two_rank_build_with_exchange(tmp_path, n_groups):
+    """6 groups: 3 per rank, scored in 3 pieces each; 3 groups: shards of 2 and 1 -- the ranks agree on ONE piece (an
+    uneven piece count would desynchronise the collectives); 11 groups: 6 and 5, four pieces each."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     world = 2
-    mp.spawn(_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    sigma, k, n_groups, mpg, sites = 4, 8, 6, 2, 120
+    mp.spawn(_rank_worker, args=(world, port, str(tmp_path), n_groups), nprocs=world, join=True)
+    sigma, k, mpg, sites = 4, 8, 2, 120
     mats = synth_matrices(n_groups * mpg, sites, sigma, 0.1, 4242)
     groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 50, mpg)
     full, emitted = oracle_db(mats, groups, k, co.log_threshold(1.5, sigma, k))
