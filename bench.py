@@ -156,11 +156,12 @@ def main():
         b_alg = b_alg * args.steps / max(launches, 1)
         achieved = b_alg / (avg_main_ms * 1e-3) / 1e9 if avg_main_ms > 0 else 0.0
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        # written by tools/pmc_traffic.py from rocprofv3 --pmc passes (cfg2: pmc_traffic.json, others: pmc_traffic_<config>.json)
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == "cfg2" else f"pmc_traffic_{args.config}.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if (tj.get("workload") == args.config and not args.groups and not args.alpha
+                if (tj.get("workload") == args.config and not args.groups and not args.alpha and not args.variant
                         and tj.get("kernel", "").startswith(main_kernel.split("_kernel")[0])):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
