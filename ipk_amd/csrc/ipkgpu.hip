@@ -1118,17 +1118,26 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
         ev_score.push_back({s0, s1});
         res->score_launches += 1;
 
-        const uint32_t n_chunks = gb * cpg;
-        if (ctx->mask_valid)
-            hipLaunchKernelGGL(count_chunks_mask_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream,
-                               ctx->mask.as<uint32_t>(), ctx->mask_words, cpg, ctx->counts.as<uint32_t>());
-        else
-            hipLaunchKernelGGL(count_chunks_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream,
-                               ctx->table.as<uint32_t>(), pl.table_size, cpg, ctx->counts.as<uint32_t>());
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                           ctx->counts.as<uint32_t>(), (uint64_t)n_chunks, total_entries, ctx->offsets.as<uint64_t>());
+        const uint32_t n_chunks = ctx->table_compressed ? gb * ctx->comp_nb : gb * cpg;    // compressed form: one item per slice
+        const uint32_t per_group = ctx->table_compressed ? ctx->comp_nb : cpg;
+        if (ctx->table_compressed) {
+            RC_TRY(ensure(ctx, ctx->offsets, ((size_t)n_chunks + 1) * 8));
+            RC_TRY(scan_u32(ctx, ctx->ucnt.as<uint32_t>(), n_chunks, ctx->offsets.as<uint64_t>()));
+            if (total_entries)
+                hipLaunchKernelGGL(add_base_kernel, dim3((n_chunks + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                                   ctx->offsets.as<uint64_t>(), (uint64_t)n_chunks + 1, total_entries);
+        } else {
+            if (ctx->mask_valid)
+                hipLaunchKernelGGL(count_chunks_mask_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream,
+                                   ctx->mask.as<uint32_t>(), ctx->mask_words, cpg, ctx->counts.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(count_chunks_kernel, dim3(n_chunks), dim3(256), 0, ctx->stream,
+                                   ctx->table.as<uint32_t>(), pl.table_size, cpg, ctx->counts.as<uint32_t>());
+            hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                               ctx->counts.as<uint32_t>(), (uint64_t)n_chunks, total_entries, ctx->offsets.as<uint64_t>());
+        }
         hipLaunchKernelGGL(gather_offsets_kernel, dim3((gb + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                           ctx->offsets.as<uint64_t>(), cpg, gb + 1, ctx->goff.as<uint64_t>());
+                           ctx->offsets.as<uint64_t>(), per_group, gb + 1, ctx->goff.as<uint64_t>());
         HIP_TRY(ctx, hipGetLastError());
         std::vector<uint64_t> goff((size_t)gb + 1);
         HIP_TRY(ctx, hipMemcpyAsync(goff.data(), ctx->goff.p, ((size_t)gb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1154,11 +1163,11 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
         if (ctx->table_compressed) {
             const CompTable ct = comp_table(ctx);
             if (sigma == 4)
-                hipLaunchKernelGGL(write_chunks_c_kernel<4>, dim3(n_chunks), dim3(256), 0, ctx->stream, ct,
-                                   pl.table_size, cpg, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);
+                hipLaunchKernelGGL(write_group_c_kernel<4>, dim3(n_chunks), dim3(256), 0, ctx->stream, ct,
+                                   pl.table_size, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);
             else
-                hipLaunchKernelGGL(write_chunks_c_kernel<20>, dim3(n_chunks), dim3(256), 0, ctx->stream, ct,
-                                   pl.table_size, cpg, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);
+                hipLaunchKernelGGL(write_group_c_kernel<20>, dim3(n_chunks), dim3(256), 0, ctx->stream, ct,
+                                   pl.table_size, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);
         } else if (sigma == 4)
             hipLaunchKernelGGL(write_chunks_kernel<4>, dim3(n_chunks), dim3(256), 0, ctx->stream, ctx->table.as<uint32_t>(),
                                pl.table_size, cpg, (int)k, ctx->offsets.as<uint64_t>(), res->d_keys, res->d_scores);

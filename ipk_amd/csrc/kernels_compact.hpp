@@ -119,34 +119,49 @@ __global__ __launch_bounds__(256) void count_chunks_mask_kernel(const uint32_t* 
     if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// Group-major CSR straight from the compressed form: a (group, bucket) slice already holds its non-empty slots' scores in
+// key order, and the slices of a group follow each other in key order, so the CSR position of a slice is the exclusive
+// scan of the slices' entry counts (ucnt).  One workgroup per slice: keys from the occupancy bits, scores decoded.
 template <int SIGMA>
-__global__ __launch_bounds__(256) void write_chunks_c_kernel(CompTable ct, uint64_t table_size, uint32_t chunks_per_group, int k,
-                                                             const uint64_t* __restrict__ offsets,
-                                                             uint32_t* __restrict__ keys, float* __restrict__ scores)
+__global__ __launch_bounds__(256) void write_group_c_kernel(CompTable ct, uint64_t table_size, int k,
+                                                            const uint64_t* __restrict__ offsets,      // [slices + 1]
+                                                            uint32_t* __restrict__ keys, float* __restrict__ scores)
 {
-    __shared__ uint32_t wcnt[4];
-    const uint32_t g = blockIdx.x / chunks_per_group, c = blockIdx.x - g * chunks_per_group;
-    const uint64_t s0 = (uint64_t)c * CHUNK;
-    const uint32_t n = (uint32_t)min((uint64_t)CHUNK, table_size - s0);
-    uint64_t out = offsets[blockIdx.x];
+    constexpr uint32_t MAXBLK = 512;                                   // TBL <= 32768 slots
+    __shared__ uint64_t smask[MAXBLK];
+    __shared__ uint32_t srank[MAXBLK];
+    const uint32_t gb = blockIdx.x, g = gb / ct.NB, b = gb - g * ct.NB;
+    const uint64_t key0 = (uint64_t)b * ct.TBL;
+    const uint32_t nslots = (uint32_t)min((uint64_t)ct.TBL, table_size - key0), nblk = (nslots + 63) / 64;
+    const uint32_t* __restrict__ vals = reinterpret_cast<const uint32_t*>(ct.pool + ct.off[(size_t)gb * ct.stride]);
+    const uint32_t* mrow = ct.mask + (size_t)g * ct.mask_words + (key0 >> 5);
+    const uint32_t* rrow = ct.rank + (size_t)g * (ct.mask_words / 2) + (key0 >> 6);
+    for (uint32_t i = threadIdx.x; i < nblk; i += 256) {               // the slice's bits and ranks: coalesced, once
+        smask[i] = (uint64_t)mrow[2 * i] | ((uint64_t)mrow[2 * i + 1] << 32);
+        srank[i] = rrow[i];
+    }
+    __syncthreads();
+    const uint64_t out = offsets[gb];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
-        const uint32_t i = i0 + threadIdx.x;
-        uint32_t v = 0;
-        if (i < n) v = ct.slot(g, s0 + i0 + wave * 64, lane);
-        const uint64_t m = __ballot(v != 0u);
-        if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
+    // eight blocks per trip: their value loads are in flight together
+    constexpr uint32_t UB = 8;
+    for (uint32_t blk0 = wave * UB; blk0 < nblk; blk0 += 4 * UB) {
+        uint32_t pos[UB], v[UB];
+        bool has[UB];
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) { const uint32_t x = wcnt[q]; total += x; if (q < wave) before += x; }
-        if (v != 0u) {
-            const uint64_t pos = out + before + mbcnt(m);
-            keys[pos] = pack_code<SIGMA>((uint32_t)(s0 + i), k);
-            scores[pos] = __uint_as_float(dec_score_bits(v));
+        for (uint32_t u = 0; u < UB; ++u) {
+            const uint32_t blk = blk0 + u;
+            const uint64_t m = blk < nblk ? smask[blk] : 0ull;
+            has[u] = (m >> lane) & 1ull;
+            pos[u] = (blk < nblk ? srank[blk] : 0u) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            v[u] = has[u] ? vals[pos[u]] : 0u;
         }
-        out += total;
-        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < UB; ++u)
+            if (has[u]) {
+                keys[out + pos[u]] = pack_code<SIGMA>((uint32_t)(key0 + (blk0 + u) * 64 + lane), k);
+                scores[out + pos[u]] = __uint_as_float(dec_score_bits(v[u]));
+            }
     }
 }
 
