@@ -16,6 +16,11 @@
  *
  * Threading: one host thread per context; calls on a context are serialised by the caller.
  * One context drives one GPU (one process per GPU; multi-GPU sharding is by branch group).
+ *
+ * Streams: a context works on its OWN non-blocking HIP stream.  Device buffers handed in by raw
+ * pointer (logp_dev, counts_dev, entries_dev ...) must be complete before the call: synchronise the
+ * stream that produced them (hipStreamSynchronize / hipEventSynchronize) first.  Every call returns
+ * after its device work has finished, so results may be read from any stream afterwards.
  */
 #ifndef IPKGPU_H
 #define IPKGPU_H

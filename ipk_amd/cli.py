@@ -59,7 +59,7 @@ def ipk():
 @click.option("--on-disk", is_flag=True, help="(ignored: the GPU build batches groups by HBM instead)")
 @click.option("--mapping", type=click.Path(exists=True), required=True,
               help="TSV: AR node label <TAB> branch post-order id, one line per ghost node")
-@click.option("--num-tree-nodes", type=int, default=0, help="node count of the original tree (MIF0's N); default 2*branches+1")
+@click.option("--num-tree-nodes", type=int, default=0, help="node count of the original tree (MIF0's N, db_builder.cpp:261); default: branch groups + 1 (every non-root node has a group)")
 @click.option("--device", type=int, default=None, help="GPU index [0; LOCAL_RANK under torchrun]")
 def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, alpha, categories, k, model, convert_uo,
           no_reduction, reduction_ratio, omega, filter_, mu, ghosts, use_unrooted, merge_branches, ar_dir, ar_only,
@@ -126,7 +126,7 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
         mats = torch.from_numpy(np.ascontiguousarray(mats)).cuda()
     db, parts = distributed.build_db_shard(eng, mats, np.array(branches, dtype=np.uint32), k, log_eps, sigma, dist, world, rank)
     t_score = time.time() - t0
-    n_nodes = num_tree_nodes or 2 * len(group_order) + 1
+    n_nodes = num_tree_nodes or len(group_order) + 1          # groups = the non-root nodes (db_builder.cpp:524-553)
     t0 = time.time()
     if filter_ == "mif0":
         db.filter_mif0(eng, n_nodes, ipk_amd.score_threshold(omega, sigma, k))

@@ -7,18 +7,23 @@
 //   H   = N h(t) ; for every entry: H = H - h(t) + h(s_i / S)             (:91-108)
 //   fv  = S * (H - log2 N)                                                (:110-115)
 // N = total number of groups (= node count of the original tree, db_builder.cpp:261), n = entries of
-// the k-mer.  One wavefront per k-mer; lanes stride the entries, partial sums are combined with
-// shuffles, so the summation ORDER differs from the reference's sequential loop: values agree to
-// ~1e-13 relative, not bit for bit (tests use 1e-9).  pow/log2 are the device libm's.
+// the k-mer.  One wavefront per k-mer: the lanes evaluate pow / log2 of 64 entries at a time, then the
+// partial results are ADDED IN ENTRY ORDER by a wave-uniform serial loop (readlane), i.e. with the very
+// association of the reference's two sequential loops (:66-84, :91-108) -- the double value, its float
+// narrowing and hence the k-mer order follow the reference formula operation for operation; what can still
+// differ is the last bit of the device libm's pow/log2 against the host's.
 #pragma once
 #include "dcla_device.hpp"
 
 namespace ipkgpu {
 
-__device__ __forceinline__ double wave_sum(double v)
+// lane j's double, broadcast (j wave-uniform)
+__device__ __forceinline__ double lane_value(double v, uint32_t j)
 {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, (int)j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), (int)j);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 __device__ __forceinline__ double mif0_score(uint32_t score_bits)
@@ -34,19 +39,28 @@ __global__ __launch_bounds__(256) void mif0_kernel(const uint64_t* __restrict__ 
                                                    uint64_t n_keys, double N, double threshold,
                                                    double* __restrict__ fv64, float* __restrict__ fv32)
 {
-    const uint64_t key = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t key = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
     if (key >= n_keys) return;
     const uint32_t lane = lane_id();
     const uint64_t a = key_off[key], b = key_off[key + 1];
-    double part = 0.0;
-    for (uint64_t i = a + lane; i < b; i += 64) part += mif0_score(entries[i].y);
+    double score_sum = 0.0;                                                      // filter.cpp:66-80, in entry order
+    for (uint64_t base = a; base < b; base += 64) {
+        const uint64_t i = base + lane;
+        const double s = i < b ? mif0_score(entries[i].y) : 0.0;
+        const uint32_t cnt = (uint32_t)min((uint64_t)64, b - base);
+        for (uint32_t j = 0; j < cnt; ++j) score_sum += lane_value(s, j);
+    }
     const double n = (double)(b - a);
-    const double S = wave_sum(part) + (N - n) * threshold;
-    const double ht = shannon(threshold / S);
-    double hp = 0.0;
-    for (uint64_t i = a + lane; i < b; i += 64) hp += shannon(mif0_score(entries[i].y) / S) - ht;
-    const double H = N * ht + wave_sum(hp);
-    const double fv = S * (H - log2(N));
+    const double S = score_sum + (N - n) * threshold;                             // :84
+    const double ht = shannon(threshold / S);                                     // :87-88
+    double H = N * ht;                                                            // :91
+    for (uint64_t base = a; base < b; base += 64) {
+        const uint64_t i = base + lane;
+        const double tv = i < b ? shannon(mif0_score(entries[i].y) / S) : 0.0;   // :103-104
+        const uint32_t cnt = (uint32_t)min((uint64_t)64, b - base);
+        for (uint32_t j = 0; j < cnt; ++j) H = H - ht + lane_value(tv, j);        // :106
+    }
+    const double fv = S * (H - log2(N));                                          // :109-114
     if (lane == 0) { fv64[key] = fv; fv32[key] = (float)fv; }
 }
 

@@ -227,6 +227,9 @@ class Engine:
                     raise ValueError("device path needs a contiguous float32 CUDA tensor")
                 n_mats, sites, sigma = logp.shape
                 ptr = logp.data_ptr()
+                # the library works on its own stream: whatever produced `logp` on torch's stream must be complete
+                import torch
+                torch.cuda.current_stream().synchronize()
             else:
                 ptr = int(logp)
             if mat_group.shape != (n_mats,):
