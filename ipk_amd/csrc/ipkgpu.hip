@@ -32,6 +32,7 @@
 #include "../../include/ipkgpu.h"
 #include "dcla_device.hpp"
 #include "kernels_score.hpp"
+#include "kernels_quad.hpp"
 #include "kernels_compact.hpp"
 #include "kernels_keymajor.hpp"
 #include "kernels_filter.hpp"
@@ -452,6 +453,39 @@ template <int SIGMA, int K> uint32_t stream_nb() {
     if constexpr (TBL == 0) return 0; else return (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
 }
 
+// ---- quad kernel: pass 1 of the stream variant for DNA k = 8..12 (kernels_quad.hpp) -----------------------
+template <int SIGMA, int K> constexpr bool quad_ok() { return QuadGeo<SIGMA, K>::OK && stream_tbl<SIGMA, K>() != 0; }
+template <int SIGMA, int K> constexpr int quad_nw() { return K <= 10 ? 4 : 7; }
+template <int SIGMA, int K> constexpr int quad_tw() { return K <= 10 ? 40 : 128; }
+template <int SIGMA, int K> size_t quad_lds()
+{
+    if constexpr (!quad_ok<SIGMA, K>()) return 0;
+    else {
+        constexpr int CAP = fast_cap<SIGMA, K>();
+        constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
+        constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
+        return QuadTile<SIGMA, K, quad_tw<SIGMA, K>()>::HEAD_BYTES + (size_t)quad_nw<SIGMA, K>() * quad_wave_entries<SIGMA, K, CAP>() * 8 +
+               (size_t)quad_nw<SIGMA, K>() * NB * 8;
+    }
+}
+template <int SIGMA, int K>
+int launch_quad_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
+{
+    if constexpr (!quad_ok<SIGMA, K>()) { (void)sp; (void)n_wg; return fail(ctx, IPKGPU_ERR_INVALID, "quad kernel unsupported for this sigma/k"); }
+    else {
+        constexpr int CAP = fast_cap<SIGMA, K>();
+        constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
+        constexpr int QNW = quad_nw<SIGMA, K>(), QTW = quad_tw<SIGMA, K>();
+        const size_t lds = quad_lds<SIGMA, K>();
+        auto kern = score_quad_kernel<SIGMA, K, CAP, QTW, QNW, TBL>;
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(QNW * 64), lds, ctx->stream, sp);
+        HIP_TRY(ctx, hipGetLastError());
+        return IPKGPU_OK;
+    }
+}
+
 // ---- exact-partition variant (count -> scan -> write -> reduce), kernels_score.hpp ---------------------
 constexpr int XP_NW = 11, XP_TW = 128;   // 11 waves: what fits 160 KB of LDS at AA k=6 (12 with 64-window tiles measured equal)
 template <int SIGMA, int K> constexpr uint32_t xp_tbl()
@@ -581,6 +615,41 @@ int dispatch_stream_pass1(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const Str
 #define M_P1(S_, K_) return launch_stream_pass1<S_, K_>(ctx, sp, n_wg)
     IPK_DISPATCH(sigma, k, M_P1);
 #undef M_P1
+    return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+}
+bool quad_supported(uint32_t sigma, uint32_t k)
+{
+#define M_QOK(S_, K_) return quad_ok<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_QOK);
+#undef M_QOK
+    return false;
+}
+uint32_t quad_waves(uint32_t sigma, uint32_t k)
+{
+#define M_QNW(S_, K_) return (uint32_t)quad_nw<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_QNW);
+#undef M_QNW
+    return NW;
+}
+uint32_t quad_tile(uint32_t sigma, uint32_t k)
+{
+#define M_QTW(S_, K_) return (uint32_t)quad_tw<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_QTW);
+#undef M_QTW
+    return TW;
+}
+size_t quad_lds_bytes(uint32_t sigma, uint32_t k)
+{
+#define M_QLDS(S_, K_) return quad_lds<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_QLDS);
+#undef M_QLDS
+    return 0;
+}
+int dispatch_quad_pass1(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const StreamParams& sp, uint32_t n_wg)
+{
+#define M_Q1(S_, K_) return launch_quad_pass1<S_, K_>(ctx, sp, n_wg)
+    IPK_DISPATCH(sigma, k, M_Q1);
+#undef M_Q1
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
 }
 int dispatch_stream_pass2(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t n_gb, uint64_t T, uint32_t* table)
@@ -872,8 +941,12 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     //                     64 GB less at cfg4, 40 % fewer bytes moved; 90.5 vs 92.0 ms through dense tables)
     const bool use_xp = XNB != 0 && (ctx->opt_variant == 3 || ctx->opt_variant == 4 || (ctx->opt_variant == 0 && NBK == 0));
     const bool xp_compress = use_xp && ctx->opt_variant != 3;
-    const bool use_stream = !use_xp && NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2);
-    const uint32_t SNW = stream_waves(pl.sigma, pl.k), STW = stream_tile(pl.sigma, pl.k);
+    const bool use_stream = !use_xp && NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2 || ctx->opt_variant == 5);
+    // pass 1 of the stream variant: the quad kernel (kernels_quad.hpp) where it exists (DNA k = 8..12), variant 2 forces the
+    // first-generation score_stream_kernel, variant 5 asks for the quad kernel explicitly
+    const bool use_quad = use_stream && ctx->opt_variant != 2 && quad_supported(pl.sigma, pl.k);
+    const uint32_t SNW = use_quad ? quad_waves(pl.sigma, pl.k) : stream_waves(pl.sigma, pl.k);
+    const uint32_t STW = use_quad ? quad_tile(pl.sigma, pl.k) : stream_tile(pl.sigma, pl.k);
     const uint32_t s_tiles_per_mat = (pl.nwin + STW - 1) / STW;
     if (!xp_compress) {
         RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 4));
@@ -915,7 +988,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     // the number of chunks the data itself fills (k = 12 has 512 buckets).
     const uint64_t windows = (uint64_t)nb * pl.nwin;
     const double ppw_est = ctx->pairs_per_window > 0 ? ctx->pairs_per_window : 256.0;
-    const size_t lds_bytes = stream_lds_bytes(pl.sigma, pl.k);
+    const size_t lds_bytes = use_quad ? quad_lds_bytes(pl.sigma, pl.k) : stream_lds_bytes(pl.sigma, pl.k);
     const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / SNW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
     const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
     const uint64_t expected_chunks = (uint64_t)((double)windows * ppw_est / CH);
@@ -939,7 +1012,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const uint64_t slack = 2 * (n_waves + ovf_waves) * NBK * SUB + (n_waves + ovf_waves) * ALLOC_BATCH + 1024;
     uint64_t want = (uint64_t)((double)windows * ppw * 1.25 / CH) + slack;
     {
-        const uint64_t have = std::min<uint64_t>(ctx->pool.cap / (CH * 8), ctx->desc.cap / 8);
+        // (the pool holds one spare chunk past its last id: kernels_quad.hpp, RowAppender)
+        const uint64_t have = std::min<uint64_t>(std::max<uint64_t>(ctx->pool.cap / (CH * 8), 1) - 1, ctx->desc.cap / 8);
         // expectation without the safety margins: pairs +10 %, ONE open chunk per (wave, bucket), the id batches
         const uint64_t need = (uint64_t)((double)windows * ppw * 1.1 / CH) + (n_waves + ovf_waves) * (NBK * SUB + ALLOC_BATCH) + 1024;
         if (have >= need) want = have;
@@ -949,9 +1023,9 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         const bool forced = attempt == 0 && ctx->opt_pool_chunks > 0;
         if (forced) cap = (uint64_t)ctx->opt_pool_chunks;
         else if (cap < n_waves * NBK * SUB) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool does not fit device memory (lower workspace_bytes)");
-        RC_TRY(ensure(ctx, ctx->pool, cap * CH * 8));
+        RC_TRY(ensure(ctx, ctx->pool, (cap + 1) * CH * 8));
         RC_TRY(ensure(ctx, ctx->desc, cap * 8));
-        if (!forced) cap = std::min<uint64_t>(ctx->pool.cap / (CH * 8), ctx->desc.cap / 8);
+        if (!forced) cap = std::min<uint64_t>(ctx->pool.cap / (CH * 8) - 1, ctx->desc.cap / 8);
         RC_TRY(ensure(ctx, ctx->gbcnt, n_gb * 4));
         RC_TRY(ensure(ctx, ctx->gbcur, n_gb * 4));
         RC_TRY(ensure(ctx, ctx->gboff, (n_gb + 1) * 8));
@@ -970,10 +1044,11 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         sp.pool = ctx->pool.as<uint2>(); sp.pool_cap = (uint32_t)cap; sp.pool_next = d_pool_next;
         sp.desc = ctx->desc.as<unsigned long long>(); sp.pool_ovf = d_pool_ovf;
         sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot;
-        sp.flags = ctx->opt_variant == 0 ? 0u : (uint32_t)(ctx->opt_flags);
+        sp.flags = (uint32_t)(ctx->opt_flags);
         Stopwatch sw(ctx->stream);
         const int ev_a = sw.mark();
-        RC_TRY(dispatch_stream_pass1(ctx, pl.sigma, pl.k, sp, n_wg));
+        if (use_quad) RC_TRY(dispatch_quad_pass1(ctx, pl.sigma, pl.k, sp, n_wg));
+        else RC_TRY(dispatch_stream_pass1(ctx, pl.sigma, pl.k, sp, n_wg));
         const int ev_b = sw.mark();
         // windows whose half lists overflowed the fast path: big-list kernel.  With the queue sorted by group it
         // appends to the same pool (LDS max-reduce in pass 2); otherwise (field widths exceeded) it falls back to
@@ -998,6 +1073,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
                                                   (size_t)n_ovf, 0, 64, ctx->stream));
             StreamParams so = sp;
             so.ovf_queue = ctx->tmp_b.as<unsigned long long>();
+            // with the quad kernel the pool's pairs are counted from the chunk descriptors: the big-list kernel's own count goes nowhere
+            if (use_quad) so.emitted = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->small) + 48);
             RC_TRY(dispatch_stream_overflow(ctx, pl.sigma, pl.k, so));
         }
         uint32_t h[2] = {0, 0};
@@ -1018,7 +1095,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         RC_TRY(ensure(ctx, ctx->clist, std::max<uint64_t>(n_used, 1) * 8));
         if (n_used) {
             hipLaunchKernelGGL(chunk_hist_kernel, dim3((n_used + 255) / 256), dim3(256), 0, ctx->stream,
-                               ctx->desc.as<unsigned long long>(), n_used, ctx->gbcnt.as<uint32_t>());
+                               ctx->desc.as<unsigned long long>(), n_used, ctx->gbcnt.as<uint32_t>(),
+                               use_quad ? p.emitted : (unsigned long long*)nullptr);
             HIP_TRY(ctx, hipGetLastError());
         }
         RC_TRY(scan_u32(ctx, ctx->gbcnt.as<uint32_t>(), n_gb, ctx->gboff.as<uint64_t>()));

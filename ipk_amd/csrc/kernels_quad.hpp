@@ -1,0 +1,477 @@
+// kernels_quad.hpp -- pass 1 of the stream variant for DNA k = 8..12, rebuilt around VALU instruction count.
+//
+// score_stream_kernel (kernels_score.hpp) is bound by VALU issue: one vector instruction per SIMD every four
+// cycles, ~440 of them per window at cfg2, most of them with a quarter of the lanes doing useful work.  This
+// kernel computes the same sets with the same float operations (pk_compute.cpp:42-114) and appends them to the same
+// pair pool, but spends about half the instructions per window:
+//
+//   thresholds   every hierarchical bound of a window -- eps - (best[a] - best[b]) chains, pk_compute.cpp:54-55 --
+//                is window-uniform: one thread per window computes the window's 22 bounds once per tile into LDS;
+//                the scoring lanes fetch them with broadcast reads (LDS instructions, not VALU).
+//   child nodes  the 2- and 3-symbol nodes are evaluated for FOUR windows per wavefront, 16 lanes each: a
+//                2-symbol node is one step for four windows; a 3-symbol node evaluates its inner pair once and
+//                loops over the four states of its first column.  Survivors are compacted per window with a
+//                16-bit field of the ballot.
+//   half joins   one window at a time, both halves in one 64-candidate step (as before).
+//   final join   R (<= 32 entries in the common case) is held in registers, floor(64 / |R|) rows of L per step:
+//                no index arithmetic per step, and every lane group works on ONE row, hence one key bucket.
+//   append       slots are reserved per ROW: the row's first lane adds the row's survivor count to the bucket's
+//                {fill, chunk} word pair with one 64-bit LDS atomic and the result is broadcast to the row's
+//                lanes (ds_bpermute) -- a handful of atomics per step instead of one per pair.
+//
+// Windows whose lists exceed the fast path's capacity are queued for the big-list kernel exactly as before.
+#pragma once
+#include "kernels_score.hpp"
+
+namespace ipkgpu {
+
+// llvm.amdgcn.ballot on the i1 itself: HIP's ballot64() goes through an int and costs two extra VALU instructions
+// (v_cndmask + v_cmp) wherever the predicate is a combination of compares
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// The four child nodes of a window: LA = (0, LA), LB = (LA, LB), RA = (HL, RA), RB = (HL + RA, RB), each of 2 or 3 symbols.
+// A wavefront evaluates them for TWO windows at a time in 16-lane slots: slot = (window half, node of the step), so a
+// step runs two nodes of equal size side by side (k = 10: step 0 = LA | RA, step 1 = LB | RB).
+struct QuadNode { int J, H, TH, OFF; uint32_t F, CMUL; };
+struct QuadStep { int H, A, B; };                                  // nodes of the step (B = -1: the second slot idles)
+
+template <int SIGMA, int K>
+struct QuadGeo {
+    using D = HalvesDD<SIGMA, K>;
+    static constexpr int HL = D::HL, HR = D::HR, LA = D::LA, LB = D::LB, RA = D::RA, RB = D::RB;
+    static constexpr bool OK = SIGMA == 4 && D::OK && LA >= 2 && LA <= 3 && LB >= 2 && LB <= 3 && RA >= 2 && RA <= 3 && RB >= 2 && RB <= 3;
+    static constexpr uint32_t FLA = D::FLA, FLB = D::FLB, FRA = D::FRA, FRB = D::FRB;
+    static constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
+    static constexpr uint32_t CW = FLA + FLB + FRA + FRB;          // child entries per window
+    static constexpr int th_n(int h) { return h == 2 ? 3 : 5; }    // thresholds of a node: itself, its leaves (and inner pair)
+    static constexpr int TH0 = 2, TH1 = TH0 + th_n(LA), TH2 = TH1 + th_n(LB), TH3 = TH2 + th_n(RA);
+    static constexpr int TH_F = TH3 + th_n(RB);                    // floats per window in the threshold table (eps_l, eps_r, 4 nodes)
+    static constexpr int PADW = 1;                                 // a pair may reach one window past the tile's last one
+    static constexpr QuadNode node(int n)
+    {
+        // LB's codes carry mulR, so that L's codes come out multiplied by it (final code = L.code + R.code)
+        return n == 0 ? QuadNode{0, LA, TH0, 0, FLA, 1u}
+             : n == 1 ? QuadNode{LA, LB, TH1, (int)FLA, FLB, mulR}
+             : n == 2 ? QuadNode{HL, RA, TH2, (int)(FLA + FLB), FRA, 1u}
+                      : QuadNode{HL + RA, RB, TH3, (int)(FLA + FLB + FRA), FRB, 1u};
+    }
+    // steps: the 2-symbol nodes paired in node order, then the 3-symbol nodes
+    static constexpr int count_h(int h) { int c = 0; for (int n = 0; n < 4; ++n) c += node(n).H == h; return c; }
+    static constexpr int nth_h(int h, int i) { for (int n = 0; n < 4; ++n) if (node(n).H == h) { if (i == 0) return n; --i; } return -1; }
+    static constexpr int NS2 = (count_h(2) + 1) / 2, NS3 = (count_h(3) + 1) / 2, NSTEPS = NS2 + NS3;
+    static constexpr QuadStep step(int s)
+    {
+        return s < NS2 ? QuadStep{2, nth_h(2, 2 * s), nth_h(2, 2 * s + 1)} : QuadStep{3, nth_h(3, 2 * (s - NS2)), nth_h(3, 2 * (s - NS2) + 1)};
+    }
+    static constexpr int step_of(int n) { for (int s = 0; s < NSTEPS; ++s) if (step(s).A == n || step(s).B == n) return s; return -1; }
+    static constexpr int slot_of(int n) { return step(step_of(n)).B == n ? 1 : 0; }
+};
+
+template <int SIGMA, int K, int TW>
+struct QuadTile {
+    static constexpr int TC = TW + K - 1 + QuadGeo<SIGMA, K>::PADW;
+    static constexpr int COLS_F = TC * SIGMA;
+    static constexpr int BEST_F = ((TC + 1 + 3) / 4) * 4;
+    static constexpr int TH_FLOATS = (((TW + QuadGeo<SIGMA, K>::PADW) * QuadGeo<SIGMA, K>::TH_F + 3) / 4) * 4;
+    static constexpr int HEAD_BYTES = (COLS_F + BEST_F + TH_FLOATS) * 4;
+};
+
+template <int SIGMA, int K, int CAP>
+constexpr uint32_t quad_wave_entries()
+{
+    using Q = QuadGeo<SIGMA, K>;
+    return 2 * Q::CW + Geo<SIGMA, Q::HL, CAP>::CAPH + Geo<SIGMA, Q::HR, CAP>::CAPH;
+}
+
+// Thresholds of one node (J, H) under the node threshold e (Direct<>::eval's own expressions, dcla_device.hpp).
+template <int J, int H>
+__device__ __forceinline__ void quad_node_thresholds(const float* bs, float e, float* out)
+{
+    out[0] = e;
+    if constexpr (H == 2) {
+        out[1] = e - (bs[J + 2] - bs[J + 1]);                      // left leaf:  eps - M(right)   (:54)
+        out[2] = e - (bs[J + 1] - bs[J]);                          // right leaf: eps - M(left)    (:55)
+    } else {
+        static_assert(H == 3, "child nodes have 2 or 3 symbols");
+        const float e_leaf = e - (bs[J + 3] - bs[J + 1]);          // first column (HL = 1)
+        const float e_pair = e - (bs[J + 1] - bs[J]);              // columns J+1, J+2
+        out[1] = e_leaf;
+        out[2] = e_pair;
+        out[3] = e_pair - (bs[J + 3] - bs[J + 2]);                 // pair's left leaf
+        out[4] = e_pair - (bs[J + 2] - bs[J + 1]);                 // pair's right leaf
+    }
+}
+
+// One step: the H-symbol node of every 16-lane slot.  `base` = LDS float index of the node's first column of the
+// slot's window (cols[(window + J) * 4]); th = the node's thresholds; list = the node's list of the slot's window;
+// code16 = l16 * cmul.  Sub-step i's survivors follow sub-step i-1's in the list (ascending code order).
+template <int H>
+__device__ __forceinline__ void quad_step(const float* cols, uint32_t base, bool valid, uint64_t vmask, const float* th, uint2* list,
+                                          uint32_t l16, uint32_t slot, uint32_t lt16, uint32_t code16, uint32_t cmul, uint32_t& count)
+{
+    // count: survivors of this lane's slot (the node's list length)
+    const float e = th[0];
+    if constexpr (H == 2) {
+        const float sl = cols[base + (l16 >> 2)], sr = cols[base + 4 + (l16 & 3u)];
+        const float s = sl + sr;                                                   // pk_compute.cpp:90
+        const bool c1 = sl > th[1], c2 = sr > th[2], c3 = s > e;                   // as_column x2, :91
+        const bool pass = valid & c1 & c2 & c3;
+        const uint64_t m = vmask & ballot64(c1) & ballot64(c2) & ballot64(c3);     // (ballots of the single compares: no VALU)
+        const uint32_t x = (uint32_t)(m >> (16u * slot));
+        const uint32_t pos = (uint32_t)__popc(x & lt16);
+        if (pass) list[pos] = make_uint2(code16, __float_as_uint(s));
+        count = (uint32_t)__popc(x & 0xFFFFu);
+    } else {
+        const float sj = cols[base + 4 + (l16 >> 2)], sl2 = cols[base + 8 + (l16 & 3u)];
+        const float s2 = sj + sl2;                                                 // the inner pair (J+1, J+2)
+        const bool d1 = sj > th[3], d2 = sl2 > th[4], d3 = s2 > th[2];
+        const bool okp = valid & d1 & d2 & d3;
+        const uint64_t mp = vmask & ballot64(d1) & ballot64(d2) & ballot64(d3);
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float si = cols[base + i];
+            const float s = si + s2;                                               // :90
+            const bool c1 = si > th[1], c2 = s > e;                                // :91
+            const bool pass = okp & c1 & c2;
+            const uint64_t m = mp & ballot64(c1) & ballot64(c2);
+            const uint32_t x = (uint32_t)(m >> (16u * slot));
+            const uint32_t pos = (uint32_t)__popc(x & lt16) + run;
+            if (pass) list[pos] = make_uint2(__umul24(cmul, (uint32_t)i * 16u) + code16, __float_as_uint(s));
+            run += (uint32_t)__popc(x & 0xFFFFu);
+        }
+        count = run;
+    }
+}
+
+// A wave-uniform value that the compiler holds in a VGPR (the result of float VALU arithmetic on uniform inputs), moved
+// to an SGPR.  __builtin_amdgcn_readfirstlane is folded away when its argument is known to be uniform, which leaves loop
+// counters derived from it in VGPRs (exec-masked loops, quarter-rate v_mul_lo_u32); the asm form is opaque.
+__device__ __forceinline__ uint32_t to_sgpr(uint32_t x)
+{
+    uint32_t r;
+    asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(x));
+    return r;
+}
+
+// The pair pool as a structured buffer: record = one chunk (CH pairs = 2 KiB), so that the hardware forms
+// base + chunk * 2048 + byte_offset (buffer_store ... idxen offen) and the 64-bit address arithmetic -- four VALU instructions
+// per store -- disappears.  Range check: chunk < num_records = pool_cap + 1 (the spare chunk included).
+typedef int quad_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ quad_v4i pool_rsrc(const uint2* pool, uint32_t pool_cap)
+{
+    const unsigned long long b = (unsigned long long)pool;
+    quad_v4i r;
+    r.x = (int)(uint32_t)b;
+    r.y = (int)(((uint32_t)(b >> 32) & 0xFFFFu) | ((CH * 8u) << 16));       // base[47:32], stride = 2048, no swizzle
+    r.z = (int)(pool_cap + 1u);
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void pool_store(const quad_v4i& rsrc, uint32_t chunk, uint32_t slot, uint2 val)
+{
+    const unsigned long long addr = ((unsigned long long)(slot * 8u) << 32) | (unsigned long long)chunk;   // {index, offset}
+    const unsigned long long data = ((unsigned long long)val.y << 32) | (unsigned long long)val.x;
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 idxen offen" : : "v"(data), "v"(addr), "s"(rsrc) : "memory");
+}
+
+// floor(x / n) for 0 <= x < 128, 1 <= n <= 64, with rn = 1 / n to within a few ulp: (x + 0.5) / n is at least 1 / 128 away from every
+// integer, far more than the rounding error of the product
+__device__ __forceinline__ uint32_t div_small(float x_plus_half, float rn) { return (uint32_t)(x_plus_half * rn); }
+
+// Per-wave pair appender with one {fill, chunk} 64-bit word per key bucket (low word: pairs reserved in the open
+// chunk, high word: the chunk's id).  "No chunk" is the id pool_cap: the pool holds one spare chunk there, so a
+// store that goes through a missing chunk (initial state, exhausted pool) needs no test and harms nothing.  The
+// initial state {CH, spare} makes the first reservation roll.
+template <uint32_t NB>
+struct RowAppender {
+    const StreamParams& p;
+    unsigned long long* st;                 // [NB]
+    uint32_t g;
+    uint32_t chunk_next = 0, chunk_end = 0;
+
+    __device__ __forceinline__ void init()
+    {
+        for (uint32_t b = lane_id(); b < NB; b += 64) st[b] = ((unsigned long long)p.pool_cap << 32) | (unsigned long long)CH;
+    }
+    // bucket b's chunk is full: close it, open a new one; returns the new chunk id (pool_cap = the spare chunk if the pool ran out)
+    __device__ __forceinline__ uint32_t roll(uint32_t b)
+    {
+        const uint32_t lane = lane_id();
+        if (chunk_next == chunk_end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(p.pool_next, ALLOC_BATCH);
+            chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            chunk_end = chunk_next + ALLOC_BATCH;
+        }
+        uint32_t nid = chunk_next++;
+        if (nid >= p.pool_cap) { if (lane == 0) atomicOr(p.pool_ovf, 1u); nid = p.pool_cap; }
+        wave_lds_sync();
+        const unsigned long long old = st[b];
+        wave_lds_sync();
+        if (lane == 0) {
+            const uint32_t old_id = (uint32_t)(old >> 32);
+            if (old_id < p.pool_cap) p.desc[old_id] = ((unsigned long long)(g * NB + b) << 32) | (unsigned long long)CH;
+            st[b] = ((unsigned long long)nid << 32) | (unsigned long long)((uint32_t)old - CH);
+        }
+        wave_lds_sync();
+        return nid;
+    }
+    __device__ __forceinline__ void close()
+    {
+        wave_lds_sync();
+        for (uint32_t b = lane_id(); b < NB; b += 64) {
+            const unsigned long long s = st[b];
+            const uint32_t id = (uint32_t)(s >> 32);
+            if (id < p.pool_cap) p.desc[id] = ((unsigned long long)(g * NB + b) << 32) | (unsigned long long)min((uint32_t)s, CH);
+        }
+    }
+};
+
+template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL>
+__global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    using Q = QuadGeo<SIGMA, K>;
+    using QT = QuadTile<SIGMA, K, TW>;
+    static_assert(Q::OK, "quad kernel: DNA k = 8..12");
+    constexpr uint32_t T = ipow(SIGMA, K);
+    constexpr uint32_t NB = (T + TBL - 1) / TBL;
+    constexpr uint32_t mulR = Q::mulR;
+    static_assert(TBL % mulR == 0, "a row of the final join must stay inside one bucket");
+    constexpr uint32_t CAPL = Geo<SIGMA, Q::HL, CAP>::CAPH, CAPR = Geo<SIGMA, Q::HR, CAP>::CAPH;
+    constexpr uint32_t WS = quad_wave_entries<SIGMA, K, CAP>();
+    float* cols = reinterpret_cast<float*>(smem);
+    float* best = cols + QT::COLS_F;
+    float* thr = best + QT::BEST_F;
+    uint2* scratch_all = reinterpret_cast<uint2*>(smem + QT::HEAD_BYTES);
+    unsigned long long* state_all = reinterpret_cast<unsigned long long*>(scratch_all + (size_t)NW * WS);
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t g = blockIdx.x / p.S, seg = blockIdx.x - g * p.S;
+    const uint32_t m0 = p.gm_off[g], nm = p.gm_off[g + 1] - m0;
+    const uint32_t total_tiles = nm * p.tiles_per_mat;
+    const uint32_t t_lo = (uint32_t)(((uint64_t)total_tiles * seg) / p.S);
+    const uint32_t t_hi = (uint32_t)(((uint64_t)total_tiles * (seg + 1)) / p.S);
+
+    uint2* child = scratch_all + (size_t)wave * WS;                // [2][CW]
+    uint2* lp = child + 2 * Q::CW;                                 // L list (codes already multiplied by mulR)
+    uint2* rp = lp + CAPL;                                         // R list
+    RowAppender<NB> app{p, state_all + (size_t)wave * NB, g};
+    app.init();
+    unsigned long long emitted = 0;
+
+    // lane roles: slot = lane / 16 = (window half, node slot of the step), 16 candidates per slot
+    const uint32_t l16 = lane & 15u, slot = lane >> 4, half = lane >> 5, sb = slot & 1u;
+    const uint32_t lt16 = (1u << l16) - 1u;
+    const float lane_h = (float)lane + 0.5f;
+    const float eps = p.eps;
+    const bool st_ok = !(p.flags & 1u);
+    const quad_v4i rsrc = pool_rsrc(p.pool, p.pool_cap);
+    // per step: the node this lane's slot evaluates
+    uint32_t st_j4[Q::NSTEPS], st_th[Q::NSTEPS], st_off[Q::NSTEPS], st_cmul[Q::NSTEPS], st_code[Q::NSTEPS];
+    bool st_on[Q::NSTEPS];
+#pragma unroll
+    for (int s = 0; s < Q::NSTEPS; ++s) {
+        constexpr QuadNode none{0, 2, 0, 0, 0, 1u};
+        const QuadStep qs = Q::step(s);
+        const QuadNode na = Q::node(qs.A), nb = qs.B >= 0 ? Q::node(qs.B) : none;
+        st_j4[s] = sb ? (uint32_t)nb.J * 4u : (uint32_t)na.J * 4u;
+        st_th[s] = sb ? (uint32_t)nb.TH : (uint32_t)na.TH;
+        st_off[s] = (sb ? (uint32_t)nb.OFF : (uint32_t)na.OFF) + half * Q::CW;
+        st_cmul[s] = sb ? nb.CMUL : na.CMUL;
+        st_code[s] = l16 * st_cmul[s];
+        st_on[s] = sb ? qs.B >= 0 : true;
+    }
+
+    for (uint32_t t = t_lo; t < t_hi; ++t) {
+        const uint32_t q = t / p.tiles_per_mat, tile = t - q * p.tiles_per_mat;
+        const uint32_t mat = p.gm_list[m0 + q];
+        const uint32_t t0 = tile * TW;
+        const uint32_t nw = min((uint32_t)TW, p.nwin - t0);
+        const uint32_t ncol = nw + K - 1;
+        __syncthreads();                                   // previous tile fully consumed
+        {
+            const float4* src = reinterpret_cast<const float4*>(p.logp + ((size_t)mat * p.sites + t0) * SIGMA);
+            float4* dst = reinterpret_cast<float4*>(cols);
+            const uint32_t n4 = ncol * (SIGMA / 4);
+            for (uint32_t i = threadIdx.x; i < n4; i += NW * 64) dst[i] = src[i];
+            const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + t0;
+            for (uint32_t i = threadIdx.x; i <= ncol; i += NW * 64) best[i] = bsrc[i];
+        }
+        __syncthreads();
+        // the tile's thresholds: one thread per window
+        for (uint32_t w = threadIdx.x; w < nw; w += NW * 64) {
+            const float* bs = best + w;
+            float* o = thr + w * Q::TH_F;
+            const float eps_l = eps - (bs[K] - bs[Q::HL]);                      // pk_compute.cpp:54 at (0, K)
+            const float eps_r = eps - (bs[Q::HL] - bs[0]);                      // :55
+            o[0] = eps_l; o[1] = eps_r;
+            quad_node_thresholds<0, Q::LA>(bs, eps_l - (bs[Q::HL] - bs[Q::LA]), o + Q::node(0).TH);             // :54 at (0, HL)
+            quad_node_thresholds<Q::LA, Q::LB>(bs, eps_l - (bs[Q::LA] - bs[0]), o + Q::node(1).TH);             // :55
+            quad_node_thresholds<Q::HL, Q::RA>(bs, eps_r - (bs[K] - bs[Q::HL + Q::RA]), o + Q::node(2).TH);     // :54 at (HL, HR)
+            quad_node_thresholds<Q::HL + Q::RA, Q::RB>(bs, eps_r - (bs[Q::HL + Q::RA] - bs[Q::HL]), o + Q::node(3).TH);   // :55
+        }
+        __syncthreads();
+
+        const uint32_t npair = (nw + 1) / 2;
+        for (uint32_t pr = wave; pr < npair; pr += NW) {
+            const uint32_t wq = pr * 2;
+            const uint32_t wl = wq + half;                                       // this lane's window
+            const bool wvalid = wl < nw;
+            const float* thw = thr + __umul24(wl, (uint32_t)Q::TH_F);
+            uint32_t counts[3] = {0, 0, 0};                                      // per step: list length of this lane's slot
+            wave_lds_sync();                                                     // the previous pair's lists are consumed
+            auto run_step = [&](auto S) {
+                constexpr int s = decltype(S)::value;
+                if constexpr (s < Q::NSTEPS) {
+                    const bool valid = wvalid && st_on[s];
+                    const uint64_t vmask = ballot64(valid);
+                    const uint32_t base = wl * 4 + st_j4[s];
+                    quad_step<Q::step(s).H>(cols, base, valid, vmask, thw + st_th[s], child + st_off[s], l16, slot, lt16, st_code[s], st_cmul[s], counts[s]);
+                }
+            };
+            run_step(std::integral_constant<int, 0>{});
+            run_step(std::integral_constant<int, 1>{});
+            run_step(std::integral_constant<int, 2>{});
+            wave_lds_sync();
+            const uint32_t nwp = min(2u, nw - wq);
+
+#pragma unroll 1
+            for (uint32_t gw = 0; gw < nwp; ++gw) {
+                const uint32_t w = wq + gw;
+                // list lengths: lane (window gw, node slot) * 16 holds them
+                const uint32_t nla = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(0)], (int)(gw * 32 + Q::slot_of(0) * 16));
+                const uint32_t nlb = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(1)], (int)(gw * 32 + Q::slot_of(1) * 16));
+                const uint32_t nra = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(2)], (int)(gw * 32 + Q::slot_of(2) * 16));
+                const uint32_t nrb = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(3)], (int)(gw * 32 + Q::slot_of(3) * 16));
+                if (nla == 0 || nlb == 0 || nra == 0 || nrb == 0) continue;      // an empty half: nothing survives
+                const uint2* cw = child + gw * Q::CW;
+                const uint2 *la = cw + Q::node(0).OFF, *lb = cw + Q::node(1).OFF, *ra = cw + Q::node(2).OFF, *rb = cw + Q::node(3).OFF;
+                const float eps_l = thr[w * Q::TH_F], eps_r = thr[w * Q::TH_F + 1];
+                const uint32_t tl = nla * nlb, tr = nra * nrb;
+                uint32_t nL, nR;
+                wave_lds_sync();                                                 // the previous window's L / R are consumed
+                if (tl <= 64 && tr <= 64) {
+                    // both half joins in one step
+                    const float rnl = __builtin_amdgcn_rcpf((float)nlb), rnr = __builtin_amdgcn_rcpf((float)nrb);   // (1 ulp: ample for div_small)
+                    const uint32_t il = div_small(lane_h, rnl), jl = lane - __umul24(il, nlb);
+                    const uint32_t ir = div_small(lane_h, rnr), jr = lane - __umul24(ir, nrb);
+                    // lanes past a half's candidates read the entries that follow in LDS and are masked out of the ballots
+                    const uint2 a0 = la[il], b0 = lb[jl], a1 = ra[ir], b1 = rb[jr];
+                    const float s0 = __uint_as_float(a0.y) + __uint_as_float(b0.y);          // :90
+                    const float s1 = __uint_as_float(a1.y) + __uint_as_float(b1.y);
+                    const bool v0 = lane < tl, v1 = lane < tr, c0 = s0 > eps_l, c1 = s1 > eps_r;    // :91
+                    const bool p0 = v0 && c0, p1 = v1 && c1;
+                    const uint64_t h0 = ballot64(v0) & ballot64(c0), h1 = ballot64(v1) & ballot64(c1);
+                    if (p0) lp[mbcnt(h0)] = make_uint2(a0.x * (Q::FLB * mulR) + b0.x, __float_as_uint(s0));   // lb codes carry mulR
+                    if (p1) rp[mbcnt(h1)] = make_uint2(a1.x * Q::FRB + b1.x, __float_as_uint(s1));
+                    nL = (uint32_t)__popcll(h0); nR = (uint32_t)__popcll(h1);
+                } else {
+                    nL = join_to_list(la, nla, lb, nlb, eps_l, Q::FLB * mulR, lp, CAPL);
+                    nR = nL == LIST_OVERFLOW || nL == 0 ? nL : join_to_list(ra, nra, rb, nrb, eps_r, Q::FRB, rp, CAPR);
+                    if (nL == LIST_OVERFLOW || nR == LIST_OVERFLOW) {
+                        if (lane == 0) {
+                            const uint32_t qi = atomicAdd(p.ovf_count, 1u);
+                            p.ovf_queue[qi] = ((unsigned long long)mat << 32) | (unsigned long long)(t0 + w);
+                        }
+                        continue;
+                    }
+                }
+                nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)nL);          // wave-uniform by construction: keep them scalar
+                nR = (uint32_t)__builtin_amdgcn_readfirstlane((int)nR);
+                if (nL == 0 || nR == 0) continue;
+                wave_lds_sync();
+                if (p.flags & 4u) { emitted += nL + nR; continue; }                 // diagnostics: list building only
+                // ---- final join: a block of <= 64 entries of R in registers, floor(64 / width) rows of L per step,
+                //      two steps per trip where two remain (their LDS round trips overlap) -----------------------------
+                for (uint32_t jb = 0; jb < nR; jb += 64) {
+                    const uint32_t nRb = min(64u, nR - jb);                          // width of this block of R
+                    const float rn = __builtin_amdgcn_rcpf((float)nRb);
+                    const uint32_t rps = to_sgpr(div_small(64.5f, rn));              // rows per step
+                    const uint32_t rsel = div_small(lane_h, rn), rfirst = __umul24(rsel, nRb), col = lane - rfirst;
+                    const bool lane_ok = rsel < rps;
+                    const uint2 b = rp[jb + col];
+                    const float by = __uint_as_float(b.y);
+                    const bool is_head = lane_ok && col == 0;
+                    const uint64_t okmask = ballot64(lane_ok);
+                    const uint64_t rowbits = nRb >= 64 ? ~0ull : ((1ull << nRb) - 1ull);
+                    const uint64_t rowmask = lane_ok ? (rowbits << rfirst) : 0ull;
+                    const uint32_t rm_lo = (uint32_t)rowmask, rm_hi = (uint32_t)(rowmask >> 32);
+                    const int head_addr = (int)(rfirst << 2);
+                    const uint2* ap = lp + rsel;                                     // rows past nL read on into the R list: masked below
+                    // NS steps starting at row i0; FULL: every step has all its rows
+                    auto trip = [&](auto NSC, auto FULLC, uint32_t i0) {
+                        constexpr int NS = decltype(NSC)::value;
+                        constexpr bool FULL = decltype(FULLC)::value;
+                        uint2 a[NS]; float s[NS]; bool pass[NS], live[NS]; uint64_t m[NS]; uint64_t any = 0;
+#pragma unroll
+                        for (int u = 0; u < NS; ++u) a[u] = ap[i0 + u * rps];
+#pragma unroll
+                        for (int u = 0; u < NS; ++u) {
+                            s[u] = __uint_as_float(a[u].y) + by;                     // pk_compute.cpp:90
+                            const bool c = s[u] > eps;                               // :91
+                            if constexpr (FULL) { live[u] = lane_ok; pass[u] = lane_ok && c; m[u] = okmask & ballot64(c); }
+                            else {
+                                const uint32_t nv = min(rps, nL - i0 - u * rps) * nRb;   // live lanes of the step
+                                live[u] = lane < nv; pass[u] = live[u] && c; m[u] = ballot64(live[u]) & ballot64(c);
+                            }
+                            any |= m[u];
+                        }
+                        if (any == 0) return;
+                        uint32_t rank[NS], bk[NS]; unsigned long long got[NS];
+#pragma unroll
+                        for (int u = 0; u < NS; ++u) {
+                            const uint32_t xl = (uint32_t)m[u] & rm_lo, xh = (uint32_t)(m[u] >> 32) & rm_hi;
+                            rank[u] = __builtin_amdgcn_mbcnt_hi(xh, __builtin_amdgcn_mbcnt_lo(xl, 0u));
+                            const uint32_t rc = (uint32_t)__popc(xl) + (uint32_t)__popc(xh);
+                            bk[u] = a[u].x / TBL;
+                            asm volatile("" : "=v"(got[u]));                         // only the head lanes' values are read (bpermute below)
+                            if (is_head && live[u]) got[u] = atomicAdd(&app.st[bk[u]], (unsigned long long)rc);
+                        }
+                        uint32_t v[NS]; uint2 val[NS]; bool over[NS]; uint64_t ovf[NS]; uint64_t anyo = 0;
+#pragma unroll
+                        for (int u = 0; u < NS; ++u) {
+                            const uint32_t fill = (uint32_t)__builtin_amdgcn_ds_bpermute(head_addr, (int)(uint32_t)got[u]);
+                            const uint32_t cb = (uint32_t)__builtin_amdgcn_ds_bpermute(head_addr, (int)(uint32_t)(got[u] >> 32));
+                            v[u] = fill + rank[u];
+                            val[u] = make_uint2(a[u].x + b.x, __float_as_uint(s[u]));
+                            const bool in = v[u] < CH;
+                            if (pass[u] && in) { if (st_ok) pool_store(rsrc, cb, v[u], val[u]); }
+                            const bool oc = v[u] >= CH;
+                            over[u] = pass[u] && oc;
+                            ovf[u] = m[u] & ballot64(oc);
+                            anyo |= ovf[u];
+                        }
+                        while (anyo) {                                                // a bucket's chunk filled up: open a new one
+                            uint32_t bb = 0;
+                            bool found = false;
+#pragma unroll
+                            for (int u = 0; u < NS; ++u)
+                                if (!found && ovf[u]) { bb = (uint32_t)__builtin_amdgcn_readlane((int)bk[u], (int)(__ffsll((long long)ovf[u]) - 1)); found = true; }
+                            const uint32_t nid = app.roll(bb);
+                            anyo = 0;
+#pragma unroll
+                            for (int u = 0; u < NS; ++u) {
+                                const bool h = over[u] && bk[u] == bb;
+                                if (h) { if (st_ok) pool_store(rsrc, nid, v[u] - CH, val[u]); }
+                                ovf[u] &= ~ballot64(h);
+                                anyo |= ovf[u];
+                            }
+                        }
+                    };
+                    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                    uint32_t i0 = 0;
+                    for (; i0 + 2 * rps <= nL; i0 += 2 * rps) trip(I2{}, std::true_type{}, i0);
+                    if (i0 + rps < nL) trip(I2{}, std::false_type{}, i0);
+                    else if (i0 < nL) trip(I1{}, std::false_type{}, i0);
+                }
+            }
+        }
+    }
+    app.close();
+    if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);       // (diagnostic flag 4 only: the pairs are counted from the chunk descriptors)
+}
+
+}  // namespace ipkgpu

@@ -676,13 +676,20 @@ __global__ __launch_bounds__(256) void ovf_group_keys_kernel(const unsigned long
 }
 
 // chunk index: how many chunks each (group, bucket) has; then chunk ids grouped by (group, bucket)
+// `pairs` (optional): the pool's pair total is added there -- the quad kernel leaves the count of scored phylo-k-mers
+// (the reference's `count`, db_builder.cpp:664) to this pass instead of counting per step.
 __global__ __launch_bounds__(256) void chunk_hist_kernel(const unsigned long long* __restrict__ desc, uint32_t n,
-                                                         uint32_t* __restrict__ cnt)
+                                                         uint32_t* __restrict__ cnt, unsigned long long* __restrict__ pairs)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long d = desc[i];
+    unsigned long long d = 0;
+    if (i < n) d = desc[i];
     if ((uint32_t)d != 0u) atomicAdd(&cnt[(uint32_t)(d >> 32)], 1u);
+    if (pairs) {
+        unsigned long long c = (uint32_t)d;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if (lane_id() == 0 && c) atomicAdd(pairs, c);
+    }
 }
 __global__ __launch_bounds__(256) void chunk_scatter_kernel(const unsigned long long* __restrict__ desc, uint32_t n,
                                                             const uint64_t* __restrict__ off, uint32_t* __restrict__ cur,
