@@ -311,9 +311,12 @@ namespace {
 constexpr int TW = 128;  // windows per tile
 constexpr int NW = 8;    // wavefronts per workgroup
 
+#ifndef IPK_QCAP
+#define IPK_QCAP 160
+#endif
 template <int SIGMA, int K> constexpr int fast_cap()
 {
-    if (SIGMA == 4) return K <= 10 ? 160 : 512;
+    if (SIGMA == 4) return K <= 10 ? IPK_QCAP : 512;
     return 512;
 }
 
@@ -455,8 +458,15 @@ template <int SIGMA, int K> uint32_t stream_nb() {
 
 // ---- quad kernel: pass 1 of the stream variant for DNA k = 8..12 (kernels_quad.hpp) -----------------------
 template <int SIGMA, int K> constexpr bool quad_ok() { return QuadGeo<SIGMA, K>::OK && stream_tbl<SIGMA, K>() != 0; }
-template <int SIGMA, int K> constexpr int quad_nw() { return K <= 10 ? 4 : 7; }
-template <int SIGMA, int K> constexpr int quad_tw() { return K <= 10 ? 40 : 128; }
+// tuning knobs of the k <= 10 instantiations (build-time: -DIPK_QNW= -DIPK_QTW= -DIPK_QCAP=)
+#ifndef IPK_QNW
+#define IPK_QNW 4
+#endif
+#ifndef IPK_QTW
+#define IPK_QTW 40
+#endif
+template <int SIGMA, int K> constexpr int quad_nw() { return K <= 10 ? IPK_QNW : 7; }
+template <int SIGMA, int K> constexpr int quad_tw() { return K <= 10 ? IPK_QTW : 128; }
 template <int SIGMA, int K> size_t quad_lds()
 {
     if constexpr (!quad_ok<SIGMA, K>()) return 0;
@@ -1094,7 +1104,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         HIP_TRY(ctx, hipMemsetAsync(ctx->gbcur.p, 0, n_gb * 4, ctx->stream));
         RC_TRY(ensure(ctx, ctx->clist, std::max<uint64_t>(n_used, 1) * 8));
         if (n_used) {
-            hipLaunchKernelGGL(chunk_hist_kernel, dim3((n_used + 255) / 256), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(chunk_hist_kernel, dim3(std::min<uint32_t>((n_used + 255) / 256, 2048u)), dim3(256), 0, ctx->stream,
                                ctx->desc.as<unsigned long long>(), n_used, ctx->gbcnt.as<uint32_t>(),
                                use_quad ? p.emitted : (unsigned long long*)nullptr);
             HIP_TRY(ctx, hipGetLastError());

@@ -677,18 +677,27 @@ __global__ __launch_bounds__(256) void ovf_group_keys_kernel(const unsigned long
 
 // chunk index: how many chunks each (group, bucket) has; then chunk ids grouped by (group, bucket)
 // `pairs` (optional): the pool's pair total is added there -- the quad kernel leaves the count of scored phylo-k-mers
-// (the reference's `count`, db_builder.cpp:664) to this pass instead of counting per step.
+// (the reference's `count`, db_builder.cpp:664) to this pass instead of counting per step.  Grid-stride over the
+// descriptors with at most a few thousand workgroups: one atomic per workgroup on the total (a single word takes
+// ~88 returning atomics per microsecond chip-wide, so one per wavefront of descriptors would cost milliseconds).
 __global__ __launch_bounds__(256) void chunk_hist_kernel(const unsigned long long* __restrict__ desc, uint32_t n,
                                                          uint32_t* __restrict__ cnt, unsigned long long* __restrict__ pairs)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    unsigned long long d = 0;
-    if (i < n) d = desc[i];
-    if ((uint32_t)d != 0u) atomicAdd(&cnt[(uint32_t)(d >> 32)], 1u);
+    __shared__ unsigned long long wsum[4];
+    unsigned long long c = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned long long d = desc[i];
+        if ((uint32_t)d != 0u) atomicAdd(&cnt[(uint32_t)(d >> 32)], 1u);
+        c += (uint32_t)d;
+    }
     if (pairs) {
-        unsigned long long c = (uint32_t)d;
         for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-        if (lane_id() == 0 && c) atomicAdd(pairs, c);
+        if (lane_id() == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (t) atomicAdd(pairs, t);
+        }
     }
 }
 __global__ __launch_bounds__(256) void chunk_scatter_kernel(const unsigned long long* __restrict__ desc, uint32_t n,

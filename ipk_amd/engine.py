@@ -48,7 +48,8 @@ def load_library():
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the C ABI itself
         pass
-    L = C.CDLL(_LIB_PATH)
+    # IPKGPU_LIB: an alternative build of the same library (tuning experiments only)
+    L = C.CDLL(os.environ.get("IPKGPU_LIB") or _LIB_PATH)
     f32p, u32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     L.ipkgpu_create.restype = C.c_int
     L.ipkgpu_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
