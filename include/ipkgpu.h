@@ -256,6 +256,71 @@ int64_t ipkgpu_ar_find(const ipkgpu_ar* ar, const char* label);      /* -1 if ab
  * n_threads = 0 uses all host cores. */
 int ipkgpu_ar_read_nodes(ipkgpu_ar* ar, const uint32_t* node_idx, uint32_t n, float* out, uint32_t n_threads);
 
+/* ---- "next" row n3 (second half): reference tree, ghost nodes, node mapping (host) -------------------------- */
+
+typedef struct ipkgpu_tree ipkgpu_tree;
+typedef struct ipkgpu_ghost_plan ipkgpu_ghost_plan;
+
+/* Own newick reader (i2l::io::load_newick is un-vendored): children in file order, post-order ids from 0, quoted labels
+ * and [comments] accepted.  ipkgpu_tree_last_error(): message of the last failing ipkgpu_tree_* / ipkgpu_ghost_plan_*
+ * call of this thread. */
+int ipkgpu_tree_parse(const char* newick, ipkgpu_tree** out);
+int ipkgpu_tree_load(const char* path, ipkgpu_tree** out);
+void ipkgpu_tree_free(ipkgpu_tree* t);
+const char* ipkgpu_tree_last_error(void);
+uint32_t ipkgpu_tree_num_nodes(const ipkgpu_tree* t);
+uint32_t ipkgpu_tree_num_leaves(const ipkgpu_tree* t);
+int ipkgpu_tree_is_rooted(const ipkgpu_tree* t);                      /* root has exactly two children */
+const char* ipkgpu_tree_label(const ipkgpu_tree* t, uint32_t postorder_id);
+int64_t ipkgpu_tree_parent(const ipkgpu_tree* t, uint32_t postorder_id);   /* post-order id of the parent, -1 for the root */
+double ipkgpu_tree_branch_length(const ipkgpu_tree* t, uint32_t postorder_id);
+const char* ipkgpu_tree_newick(ipkgpu_tree* t);                       /* owned by the tree, valid until the next call */
+/* The database header's tree index (db_builder.cpp:192-197): per node in post-order, the size of its subtree and the
+ * total branch length below it.  Arrays of ipkgpu_tree_num_nodes() elements. */
+int ipkgpu_tree_index(const ipkgpu_tree* t, uint32_t* num_nodes, double* subtree_length);
+/* tree_extender::extend (extended_tree.cpp:76-150): ghost nodes <counter>_X0 / _X1 (+ dummy leaves _X2 / _X3) on every
+ * non-root branch, counter from node_count + 1; the result remembers ghost label -> original post-order id. */
+int ipkgpu_tree_extend(const ipkgpu_tree* original, ipkgpu_tree** extended);
+/* reroot_tree (extended_tree.cpp:186-205), applied to the AR tree when the reference tree is rooted (main.cpp:172-178). */
+int ipkgpu_tree_reroot(ipkgpu_tree* t);
+/* get_ghost_ids + group_ghost_ids (db_builder.cpp:495-553) + map_nodes (ar.cpp:790-834): the ghost nodes in the order
+ * explore_kmers scores them, each with its label in the AR output and its branch id = mat_group of ipkgpu_score_groups.
+ * strategy: 0 both, 1 inner only (_X0), 2 outer only (_X1).  ar_tree may be NULL (AR labels = extended labels). */
+int ipkgpu_ghost_plan_make(const ipkgpu_tree* original, const ipkgpu_tree* extended, const ipkgpu_tree* ar_tree, int strategy,
+                           ipkgpu_ghost_plan** out);
+void ipkgpu_ghost_plan_free(ipkgpu_ghost_plan* p);
+uint32_t ipkgpu_ghost_plan_size(const ipkgpu_ghost_plan* p);
+const char* ipkgpu_ghost_plan_ext_label(const ipkgpu_ghost_plan* p, uint32_t i);
+const char* ipkgpu_ghost_plan_ar_label(const ipkgpu_ghost_plan* p, uint32_t i);
+const uint32_t* ipkgpu_ghost_plan_branches(const ipkgpu_ghost_plan* p);
+
+/* ---- "next" row n2: the database file (db_builder.cpp:145-146,176-177,297-306,323-327) ------------------------ */
+
+/* Header fields in the order of i2l::ipk_header as db_builder.cpp:297-305 fills it. */
+typedef struct ipkgpu_db_header {
+    const char* sequence_type;            /* seq_type::name: "DNA" | "AA" */
+    uint64_t tree_index_size;             /* nodes of the original tree */
+    const uint32_t* tree_num_nodes;       /* [tree_index_size] (ipkgpu_tree_index) */
+    const double* tree_subtree_length;    /* [tree_index_size] */
+    const char* newick;                   /* the original tree */
+    uint64_t kmer_size;
+    float omega;
+} ipkgpu_db_header;
+
+/* save_header + save_phylo_kmer for every k-mer in filter order (db_builder.cpp:297-306,323-327), streamed from device
+ * memory: the records are packed on the GPU in pieces, copied through pinned buffers and written while the next piece is
+ * being packed.  Needs ipkgpu_db_filter_mif0 first.  Byte layout: ipk_amd/csrc/ipk_format.hpp -- i2l and Boost are
+ * un-vendored, so the layout is a reconstruction (Boost binary_oarchive primitives) and NOT pinned against a real .ipk. */
+int ipkgpu_db_write(ipkgpu_ctx* ctx, ipkgpu_db* db, const ipkgpu_db_header* header, const char* path, uint64_t* bytes_written);
+/* The same serialiser over host arrays (merged shards of several GPUs, or a filter computed on the host):
+ * entries u32 [n][2] = (branch, score bits); order = positions of the k-mers in output order (NULL: as stored). */
+int ipkgpu_db_write_host(const ipkgpu_db_header* header, uint64_t n_keys, const uint32_t* keys, const uint64_t* key_offsets,
+                         const uint32_t* entries, const float* filter_values, const uint32_t* order, const char* path,
+                         uint64_t* bytes_written);
+const char* ipkgpu_db_write_last_error(void);
+/* seconds of the last ipkgpu_db_write of this context: 0 = total, 1 = device packing + copies (waited for), 2 = file writes */
+double ipkgpu_db_write_time_s(const ipkgpu_ctx* ctx, int which);
+
 #ifdef __cplusplus
 }
 #endif

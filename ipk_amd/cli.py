@@ -1,17 +1,21 @@
-"""`ipk build`-compatible command line for the MI355X engine.
+"""`ipk build`-compatible command line for the MI355X engine (SURVEY.md section 8f, rows n3 + n4).
 
 Option names and defaults follow the reference wrapper (ipk.py:70-230 -> argv table ipk.py:292-329,
-ipk/src/command_line.cpp:83-147).  Only the stages this repository owns run here: reading the RAxML-ng
-ancestral probabilities from --ar-dir, scoring on the GPU, MIF0 filter, database file.  Alignment
-reduction, tree extension, ancestral reconstruction and ghost-node mapping are IPK's host stages and out
-of scope: their options are accepted for command-line compatibility and ignored,
-and the ghost-node -> branch mapping they would produce is read from --mapping.
+ipk/src/command_line.cpp:83-147), and so does the flow of main.cpp:129-200 for the stages this repository owns:
 
-  python -m ipk_amd.cli build -r aln.fasta -t tree.nwk -w work --ar-dir work/AR --mapping work/ghosts.tsv -k 10
+  reference tree (-t) -> ghost nodes (extended_tree.cpp:76-162; saved as workdir/extended_trees/extended_tree.newick)
+  -> AR outputs found by suffix in --ar-dir (ar.cpp:611-640: *.raxml.ancestralProbs, *.raxml.ancestralTree)
+  -> AR tree rerooted if the reference tree is rooted (main.cpp:172-178) -> extended/AR node mapping (ar.cpp:790-834)
+  -> ghost groups (db_builder.cpp:495-553) -> GPU scoring -> MIF0 filter -> database file.
 
---mapping: TSV `ar_node_label <TAB> branch_postorder_id`, one line per ghost node (X0/X1), in the order the
-extended tree lists them (= group order, db_builder.cpp:576-627).  --ghosts inner-only / outer-only keep
-labels ending in _X0 / _X1 only (db_builder.cpp:495-507) when the labels carry those suffixes.
+Alignment reduction/extension and RUNNING the ancestral reconstruction are IPK's host stages and out of scope
+(DESIGN.md): their options are accepted for command-line compatibility and ignored; the AR outputs must exist (e.g. from
+`ipk.py build --ar-only` of the reference, or raxml-ng run on the saved extended tree).
+
+  ipk.py build -r aln.fasta -t tree.nwk -w work --ar-dir work/AR -k 10
+
+--mapping (optional, not in the reference): TSV `ar_node_label <TAB> branch_postorder_id` per ghost node in scoring order;
+replaces the tree-derived plan (synthetic inputs without trees).
 """
 import glob
 import os
@@ -48,18 +52,18 @@ def ipk():
 @click.option("--ghosts", type=click.Choice(["inner-only", "outer-only", "both"]), default="both", show_default=True)
 @click.option("--use-unrooted", is_flag=True, help="(ignored)")
 @click.option("--merge-branches", is_flag=True, help="unsupported (as in the reference, main.cpp:31-37)")
-@click.option("--ar-dir", type=click.Path(exists=True, file_okay=False), required=True,
-              help="directory holding <prefix>.raxml.ancestralProbs")
+@click.option("--ar-dir", type=click.Path(exists=True, file_okay=False), default=None,
+              help="directory holding <prefix>.raxml.ancestralProbs / .raxml.ancestralTree [searched in the workdir if absent]")
 @click.option("--ar-only", is_flag=True, help="(ignored)")
 @click.option("--ar-config", type=click.Path(), help="(ignored)")
 @click.option("--keep-positions", is_flag=True, help="unsupported on this engine")
 @click.option("--uncompressed", is_flag=True, help="(ignored, as in the reference)")
 @click.option("--threads", type=int, default=1, show_default=True, help="host threads of the probability loader")
-@click.option("-o", "--output", default=None, help="output file [workdir/DB.ipkgpu]")
+@click.option("-o", "--output", default=None, help="output file [workdir/DB.ipk]")
 @click.option("--on-disk", is_flag=True, help="(ignored: the GPU build batches groups by HBM instead)")
-@click.option("--mapping", type=click.Path(exists=True), required=True,
-              help="TSV: AR node label <TAB> branch post-order id, one line per ghost node")
-@click.option("--num-tree-nodes", type=int, default=0, help="node count of the original tree (MIF0's N, db_builder.cpp:261); default: branch groups + 1 (every non-root node has a group)")
+@click.option("--mapping", type=click.Path(exists=True), default=None,
+              help="TSV: AR node label <TAB> branch post-order id, one line per ghost node (instead of the tree-derived plan)")
+@click.option("--num-tree-nodes", type=int, default=0, help="node count of the original tree (MIF0's N, db_builder.cpp:261); default: the reference tree's, or branch groups + 1 with --mapping")
 @click.option("--device", type=int, default=None, help="GPU index [0; LOCAL_RANK under torchrun]")
 def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, alpha, categories, k, model, convert_uo,
           no_reduction, reduction_ratio, omega, filter_, mu, ghosts, use_unrooted, merge_branches, ar_dir, ar_only,
@@ -71,28 +75,58 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
 
     if merge_branches or keep_positions:
         raise click.UsageError("--merge-branches / --keep-positions are not supported")
+    from ipk_amd import tree as T
     sigma = 4 if states == "nucl" else 20
     if not 2 <= k <= ipk_amd.max_k(sigma):
         raise click.UsageError(f"k must be in [2, {ipk_amd.max_k(sigma)}] for --states {states} on this engine")
     os.makedirs(workdir, exist_ok=True)
-    output = output or os.path.join(workdir, "DB.ipkgpu")
-    probs = sorted(glob.glob(os.path.join(ar_dir, "*.raxml.ancestralProbs")))        # ar.cpp:611-640 suffix lookup
-    if not probs:
-        raise click.UsageError(f"no *.raxml.ancestralProbs in {ar_dir}")
+    output = output or os.path.join(workdir, "DB.ipk")
 
+    def find_by_suffix(suffix):                                                       # ar.cpp:458-469, :611-640
+        dirs = [ar_dir] if ar_dir else [os.path.join(workdir, "extended_trees"), os.path.join(workdir, "AR"), workdir]
+        for d in dirs:
+            hits = sorted(glob.glob(os.path.join(d, "*" + suffix)))
+            if hits:
+                return hits[0]
+        raise click.UsageError(f"Could not find \"*{suffix}\" in {dirs}: this build does not run the ancestral reconstruction itself")
+
+    probs_file = find_by_suffix(".raxml.ancestralProbs")
+    orig = ext = None
+    tree_index, newick, n_tree_nodes = [], "", 0
+    if reftree:
+        orig = T.Tree.load(reftree)
+        if not orig.is_rooted and not use_unrooted:                                   # extended_tree.cpp:169-177
+            raise click.UsageError("This reference tree is not rooted. Please provide a rooted tree or provide --use-unrooted. "
+                                   "WARNING! This may impact placement accuracy.")
+        tree_index, newick, n_tree_nodes = orig.index(), orig.newick(), orig.num_nodes
     labels, branches = [], []
-    for line in open(mapping):
-        line = line.rstrip("\n")
-        if not line or line.startswith("#"):
-            continue
-        lab, br = line.split("\t")[:2]
-        if ghosts == "inner-only" and not lab.endswith("_X0"):
-            continue
-        if ghosts == "outer-only" and not lab.endswith("_X1"):
-            continue
-        labels.append(lab); branches.append(int(br))
+    if mapping:
+        for line in open(mapping):
+            line = line.rstrip("\n")
+            if not line or line.startswith("#"):
+                continue
+            lab, br = line.split("\t")[:2]
+            if ghosts == "inner-only" and not lab.endswith("_X0"):
+                continue
+            if ghosts == "outer-only" and not lab.endswith("_X1"):
+                continue
+            labels.append(lab); branches.append(int(br))
+    else:
+        if orig is None:
+            raise click.UsageError("-t/--reftree is required (or --mapping for inputs without trees)")
+        ext = orig.extend()
+        ext_dir = os.path.join(workdir, "extended_trees")                               # main.cpp:39-46
+        os.makedirs(ext_dir, exist_ok=True)
+        if int(os.environ.get("RANK", "0")) == 0:
+            with open(os.path.join(ext_dir, "extended_tree.newick"), "w") as fh:
+                fh.write(ext.newick() + "\n")
+        ar_tree = T.Tree.load(find_by_suffix(".raxml.ancestralTree"))
+        if orig.is_rooted and not ar_tree.is_rooted:                                   # main.cpp:172-178
+            ar_tree.reroot()
+        for _ext_label, ar_label, branch in T.ghost_plan(orig, ext, ar_tree, ghosts):
+            labels.append(ar_label); branches.append(branch)
     if not labels:
-        raise click.UsageError("the mapping selects no ghost nodes")
+        raise click.UsageError("no ghost nodes selected")
 
     # several GPUs: one process per GPU (torchrun); branch groups are split into contiguous ranges of the group
     # order, every rank scores its range, the k-mer-keyed exchange (RCCL) leaves rank r with the k-mers code % P == r
@@ -115,7 +149,7 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
     labels, branches = [labels[i] for i in sel], [all_branches[i] for i in sel]
 
     t0 = time.time()
-    arp = AncestralProbs(probs[0], sigma)
+    arp = AncestralProbs(probs_file, sigma)
     mats = arp.read(labels, n_threads=max(1, threads)) if labels else np.zeros((0, arp.sites, sigma), np.float32)
     t_load = time.time() - t0
     log_eps = ipk_amd.log_threshold(omega, sigma, k)
@@ -126,23 +160,30 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
         mats = torch.from_numpy(np.ascontiguousarray(mats)).cuda()
     db, parts = distributed.build_db_shard(eng, mats, np.array(branches, dtype=np.uint32), k, log_eps, sigma, dist, world, rank)
     t_score = time.time() - t0
-    n_nodes = num_tree_nodes or len(group_order) + 1          # groups = the non-root nodes (db_builder.cpp:524-553)
+    # MIF0's N = _original_tree.get_node_count() (db_builder.cpp:261); without a tree: groups = the non-root nodes (:524-553)
+    n_nodes = num_tree_nodes or n_tree_nodes or len(group_order) + 1
     t0 = time.time()
+    seq_name = "DNA" if sigma == 4 else "AA"
     if filter_ == "mif0":
         db.filter_mif0(eng, n_nodes, ipk_amd.score_threshold(omega, sigma, k))
-        fv, order = db.filter_values().copy(), db.filter_order().copy()
-    else:
-        # random_filter (filter.cpp:122-145) draws uniform(0, 1) from std::default_random_engine(42) in the hash map's
-        # iteration order, which no other build reproduces; here: one fixed draw per k-mer CODE, so the file does not
-        # depend on how the k-mers are sharded
-        fv = (dbfile.splitmix_unit(db.keys()) if db.num_keys else np.zeros(0)).astype(np.float32)
-        order = np.argsort(dbfile.filter_sort_code(fv, db.keys()), kind="stable")
     t_filter = time.time() - t0
-    newick = open(reftree).read().strip() if reftree and os.path.exists(reftree) else ""
-    br, sc = db.entries()
     t0 = time.time()
-    totals = distributed.write_db_file(output, "DNA" if sigma == 4 else "AA", [], newick, k, omega, db.keys(), db.key_offsets(),
-                                       br, sc, fv, order, workdir, dist, world, rank)
+    if world == 1 and filter_ == "mif0":
+        # one GPU: records packed on the device in filter order and streamed to the file (ipkgpu_db_write)
+        dbfile.write_db_device(eng, db, output, seq_name, tree_index, newick, k, omega)
+        totals = (db.num_keys, db.num_entries)
+    else:
+        if filter_ == "mif0":
+            fv, order = db.filter_values().copy(), db.filter_order().copy()
+        else:
+            # random_filter (filter.cpp:122-145) draws uniform(0, 1) from std::default_random_engine(42) in the hash map's
+            # iteration order, which no other build reproduces; here: one fixed draw per k-mer CODE, so the file does not
+            # depend on how the k-mers are sharded
+            fv = (dbfile.splitmix_unit(db.keys()) if db.num_keys else np.zeros(0)).astype(np.float32)
+            order = np.argsort(dbfile.filter_sort_code(fv, db.keys()), kind="stable")
+        br, sc = db.entries()
+        totals = distributed.write_db_file(output, seq_name, tree_index, newick, k, omega, db.keys(), db.key_offsets(),
+                                           br, sc, fv, order, workdir, dist, world, rank)
     t_write = time.time() - t0
     emitted = parts.emitted
     if world > 1:

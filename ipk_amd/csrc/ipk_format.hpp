@@ -1,0 +1,66 @@
+// ipk_format.hpp -- the ONE place that knows the bytes of the database file.
+//
+// IPK streams its database through i2l::save_header / i2l::save_phylo_kmer over a boost::archive::binary_oarchive opened on
+// the output file (ipk/src/db_builder.cpp:145-146,176-177,297-306,323-327).  i2l and Boost are not in the reference tree,
+// so this layout is a RECONSTRUCTION -- unpinned: no real .ipk file or i2l source was available to check it against.  It
+// follows what the call sites fix (field order of ipk_header at db_builder.cpp:297-305; per k-mer: key, filter value,
+// entries of (branch, score) at :323-327) and writes every primitive the way Boost's binary_oarchive does on x86-64
+// (native little endian; std::string = u64 length + bytes; size_t = u64).  A maintainer with i2l at hand changes only
+// this header.
+//
+//   preamble  u64 22, "serialization::archive", u16 library version, u8 sizeof(int), u8 sizeof(long), u8 sizeof(float),
+//             u8 sizeof(double), i32 1          (basic_binary_oarchive::init + basic_binary_oprimitive::init)
+//   header    string sequence_type ; u64 n ; n x { u64 num_nodes ; f64 subtree_branch_length } ; string newick ;
+//             u64 kmer_size ; f32 omega ; u64 total_num_kmers ; u64 total_num_entries
+//   k-mers    per k-mer in filter order: u32 key ; f32 filter_value ; u64 n ; n x { u32 branch ; f32 score }
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#if defined(__HIPCC__)
+#define IPKFMT_HD __host__ __device__
+#else
+#define IPKFMT_HD
+#endif
+
+namespace ipkfmt {
+
+constexpr uint16_t BOOST_ARCHIVE_LIBRARY_VERSION = 19;      // Boost 1.74 .. 1.83 (ASSUMPTION: the build's Boost is unknown)
+constexpr uint64_t RECORD_HEAD_BYTES = 16;                   // key, filter value, entry count
+constexpr uint64_t ENTRY_BYTES = 8;                          // branch, score
+
+IPKFMT_HD inline uint64_t record_bytes(uint64_t n_entries) { return RECORD_HEAD_BYTES + ENTRY_BYTES * n_entries; }
+
+// the four 32-bit words of a record's head
+IPKFMT_HD inline void record_head(uint32_t key, uint32_t fv_bits, uint64_t n_entries, uint32_t (&w)[4])
+{
+    w[0] = key; w[1] = fv_bits; w[2] = (uint32_t)n_entries; w[3] = (uint32_t)(n_entries >> 32);
+}
+
+inline void put(std::vector<uint8_t>& o, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; o.insert(o.end(), b, b + n); }
+template <class T> inline void put_v(std::vector<uint8_t>& o, T v) { put(o, &v, sizeof v); }
+inline void put_string(std::vector<uint8_t>& o, const char* s) { const uint64_t n = s ? strlen(s) : 0; put_v<uint64_t>(o, n); put(o, s, n); }
+
+// everything in front of the first k-mer record
+inline std::vector<uint8_t> file_head(const char* sequence_type, uint64_t n_index, const uint32_t* num_nodes, const double* subtree_length,
+                                      const char* newick, uint64_t kmer_size, float omega, uint64_t total_kmers, uint64_t total_entries)
+{
+    std::vector<uint8_t> o;
+    put_string(o, "serialization::archive");
+    put_v<uint16_t>(o, BOOST_ARCHIVE_LIBRARY_VERSION);
+    put_v<uint8_t>(o, 4); put_v<uint8_t>(o, 8); put_v<uint8_t>(o, 4); put_v<uint8_t>(o, 8);
+    put_v<int32_t>(o, 1);
+    put_string(o, sequence_type);
+    put_v<uint64_t>(o, n_index);
+    for (uint64_t i = 0; i < n_index; ++i) { put_v<uint64_t>(o, num_nodes[i]); put_v<double>(o, subtree_length[i]); }
+    put_string(o, newick);
+    put_v<uint64_t>(o, kmer_size);
+    put_v<float>(o, omega);
+    put_v<uint64_t>(o, total_kmers);
+    put_v<uint64_t>(o, total_entries);
+    return o;
+}
+
+}  // namespace ipkfmt

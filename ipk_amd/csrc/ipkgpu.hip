@@ -36,6 +36,8 @@
 #include "kernels_compact.hpp"
 #include "kernels_keymajor.hpp"
 #include "kernels_filter.hpp"
+#include "kernels_dbfile.hpp"
+#include <chrono>
 
 using namespace ipkgpu;
 
@@ -78,6 +80,7 @@ struct ipkgpu_ctx {
     std::unordered_map<void*, size_t> live_blocks;
     size_t cached_bytes = 0, cache_limit = 0;
     void* small = nullptr;            // emitted (u64) @0, ovf_count (u32) @16
+    double t_write_total = 0, t_write_device = 0, t_write_file = 0;   // last ipkgpu_db_write
     int num_cu = 256;
 };
 
@@ -1895,6 +1898,145 @@ void ipkgpu_db_free(ipkgpu_db* d)
         ctx_release(d->ctx, d->d_fv64); ctx_release(d->ctx, d->d_fv32); ctx_release(d->ctx, d->d_order);
     }
     delete d;
+}
+
+}  // extern "C"
+
+// ---- "next" row n2: the database file -------------------------------------------------------------------
+namespace {
+thread_local std::string g_write_err;
+
+struct FileOut {
+    FILE* f = nullptr;
+    ~FileOut() { if (f) fclose(f); }
+    bool put(const void* p, size_t n) { return n == 0 || fwrite(p, 1, n, f) == n; }
+};
+}  // namespace
+
+extern "C" {
+
+const char* ipkgpu_db_write_last_error(void) { return g_write_err.c_str(); }
+double ipkgpu_db_write_time_s(const ipkgpu_ctx* ctx, int which)
+{
+    if (!ctx) return 0;
+    return which == 1 ? ctx->t_write_device : which == 2 ? ctx->t_write_file : ctx->t_write_total;
+}
+
+int ipkgpu_db_write_host(const ipkgpu_db_header* h, uint64_t n_keys, const uint32_t* keys, const uint64_t* key_off, const uint32_t* entries,
+                         const float* fv, const uint32_t* order, const char* path, uint64_t* bytes_written)
+{
+    if (!h || !path || (n_keys && (!keys || !key_off || !fv))) { g_write_err = "null argument"; return IPKGPU_ERR_INVALID; }
+    FileOut out;
+    out.f = fopen(path, "wb");
+    if (!out.f) { g_write_err = std::string("cannot create ") + path; return IPKGPU_ERR_INVALID; }
+    const uint64_t n_entries = n_keys ? key_off[n_keys] : 0;
+    const std::vector<uint8_t> head = ipkfmt::file_head(h->sequence_type, h->tree_index_size, h->tree_num_nodes, h->tree_subtree_length, h->newick,
+                                                        h->kmer_size, h->omega, n_keys, n_entries);
+    uint64_t total = head.size();
+    if (!out.put(head.data(), head.size())) { g_write_err = "write failed"; return IPKGPU_ERR_INVALID; }
+    std::vector<uint8_t> buf;
+    buf.reserve((size_t)16 << 20);
+    for (uint64_t i = 0; i < n_keys; ++i) {
+        const uint64_t k = order ? order[i] : i;
+        const uint64_t a = key_off[k], n = key_off[k + 1] - a;
+        uint32_t w[4];
+        uint32_t fb; memcpy(&fb, &fv[k], 4);
+        ipkfmt::record_head(keys[k], fb, n, w);
+        ipkfmt::put(buf, w, sizeof w);
+        ipkfmt::put(buf, entries + 2 * a, (size_t)(n * ipkfmt::ENTRY_BYTES));
+        if (buf.size() >= ((size_t)15 << 20)) { if (!out.put(buf.data(), buf.size())) { g_write_err = "write failed"; return IPKGPU_ERR_INVALID; } total += buf.size(); buf.clear(); }
+    }
+    if (!out.put(buf.data(), buf.size())) { g_write_err = "write failed"; return IPKGPU_ERR_INVALID; }
+    total += buf.size();
+    if (fclose(out.f) != 0) { out.f = nullptr; g_write_err = "close failed"; return IPKGPU_ERR_INVALID; }
+    out.f = nullptr;
+    if (bytes_written) *bytes_written = total;
+    return IPKGPU_OK;
+}
+
+int ipkgpu_db_write(ipkgpu_ctx* ctx, ipkgpu_db* db, const ipkgpu_db_header* h, const char* path, uint64_t* bytes_written)
+{
+    if (!ctx) return IPKGPU_ERR_INVALID;
+    if (!db || db->ctx != ctx || !h || !path) return fail(ctx, IPKGPU_ERR_INVALID, "bad argument");
+    if (db->n_keys && (!db->d_fv32 || !db->d_order)) return fail(ctx, IPKGPU_ERR_INVALID, "filter values missing: call ipkgpu_db_filter_mif0 first");
+    if (db->n_keys >= 0xFFFFFFFFull) return fail(ctx, IPKGPU_ERR_INVALID, "too many k-mers");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    double t_dev = 0, t_file = 0;
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    FileOut out;
+    out.f = fopen(path, "wb");
+    if (!out.f) return fail(ctx, IPKGPU_ERR_INVALID, "cannot create %s", path);
+    setvbuf(out.f, nullptr, _IONBF, 0);                              // the pieces are large: no second copy through stdio
+    const uint64_t n = db->n_keys;
+    const std::vector<uint8_t> head = ipkfmt::file_head(h->sequence_type, h->tree_index_size, h->tree_num_nodes, h->tree_subtree_length, h->newick,
+                                                        h->kmer_size, h->omega, n, db->n_entries);
+    uint64_t total = head.size();
+    { const auto t0 = std::chrono::steady_clock::now(); if (!out.put(head.data(), head.size())) return fail(ctx, IPKGPU_ERR_INVALID, "write failed"); t_file += since(t0); }
+    if (n) {
+        // record offsets in filter order
+        RC_TRY(ensure(ctx, ctx->tmp_a, n * 4));
+        RC_TRY(ensure(ctx, ctx->tmp_b, (n + 1) * 8));
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(db_record_sizes_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, db->d_order, db->d_key_off, n,
+                           ctx->tmp_a.as<uint32_t>());
+        HIP_TRY(ctx, hipGetLastError());
+        RC_TRY(scan_u32(ctx, ctx->tmp_a.as<uint32_t>(), n, ctx->tmp_b.as<uint64_t>()));
+        std::vector<uint64_t> rec_off(n + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(rec_off.data(), ctx->tmp_b.p, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        t_dev += since(t0);
+        // pieces of whole records, two staging buffers: piece j+1 is packed and copied while piece j is written
+        uint64_t max_rec = 0;
+        for (uint64_t i = 0; i < n; ++i) max_rec = std::max(max_rec, rec_off[i + 1] - rec_off[i]);
+        const uint64_t PIECE = std::max<uint64_t>((uint64_t)256 << 20, max_rec);
+        void* d_stage[2] = {nullptr, nullptr};
+        void* h_stage[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        struct Cleanup { ipkgpu_ctx* c; void** d; void** h; hipEvent_t* e;
+            ~Cleanup() { for (int i = 0; i < 2; ++i) { ctx_release(c, d[i]); if (h[i]) (void)hipHostFree(h[i]); if (e[i]) (void)hipEventDestroy(e[i]); } } } cleanup{ctx, d_stage, h_stage, ev};
+        const uint64_t body = rec_off[n];
+        const uint64_t stage_bytes = std::min<uint64_t>(PIECE, body);
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(ctx, ctx_alloc(ctx, &d_stage[i], std::max<uint64_t>(stage_bytes, 16)));
+            HIP_TRY(ctx, hipHostMalloc(&h_stage[i], std::max<uint64_t>(stage_bytes, 16), hipHostMallocDefault));
+            HIP_TRY(ctx, hipEventCreate(&ev[i]));
+        }
+        struct Piece { uint64_t lo, hi; };
+        std::vector<Piece> pieces;
+        for (uint64_t lo = 0; lo < n;) {
+            // largest hi with rec_off[hi] - rec_off[lo] <= PIECE
+            const uint64_t hi = (uint64_t)(std::upper_bound(rec_off.begin() + lo, rec_off.end(), rec_off[lo] + PIECE) - rec_off.begin()) - 1;
+            pieces.push_back({lo, std::max(hi, lo + 1)});
+            lo = pieces.back().hi;
+        }
+        auto launch = [&](size_t j) -> int {
+            const Piece pc = pieces[j];
+            const int b = (int)(j & 1);
+            hipLaunchKernelGGL(db_pack_kernel, dim3((uint32_t)((pc.hi - pc.lo + 3) / 4)), dim3(256), 0, ctx->stream, db->d_order, db->d_keys, db->d_key_off,
+                               db->d_entries, db->d_fv32, ctx->tmp_b.as<uint64_t>(), pc.lo, pc.hi, (unsigned char*)d_stage[b]);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(h_stage[b], d_stage[b], rec_off[pc.hi] - rec_off[pc.lo], hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ev[b], ctx->stream));
+            return IPKGPU_OK;
+        };
+        if (!pieces.empty()) RC_TRY(launch(0));
+        for (size_t j = 0; j < pieces.size(); ++j) {
+            if (j + 1 < pieces.size()) RC_TRY(launch(j + 1));
+            const auto tw = std::chrono::steady_clock::now();
+            HIP_TRY(ctx, hipEventSynchronize(ev[j & 1]));
+            t_dev += since(tw);
+            const auto tf = std::chrono::steady_clock::now();
+            const uint64_t nb = rec_off[pieces[j].hi] - rec_off[pieces[j].lo];
+            if (!out.put(h_stage[j & 1], nb)) return fail(ctx, IPKGPU_ERR_INVALID, "write failed");
+            t_file += since(tf);
+            total += nb;
+        }
+    }
+    { const auto t0 = std::chrono::steady_clock::now(); const int rc = fclose(out.f); out.f = nullptr; if (rc != 0) return fail(ctx, IPKGPU_ERR_INVALID, "close failed"); t_file += since(t0); }
+    ctx->t_write_total = since(t_begin); ctx->t_write_device = t_dev; ctx->t_write_file = t_file;
+    if (bytes_written) *bytes_written = total;
+    return IPKGPU_OK;
 }
 
 }  // extern "C"

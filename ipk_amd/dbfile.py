@@ -1,83 +1,150 @@
-"""Database file writer/reader -- NOT byte-compatible with i2l's `.ipk`.
+"""Database file: Python face of the C++ serialiser, plus a reader for the tests.
 
 IPK streams its database through i2l::save_header / save_phylo_kmer over a Boost binary_oarchive
-(ipk/src/db_builder.cpp:145-146,176-177,297-306,323-327).  Both i2l and Boost.Serialization are absent
-from the reference tree, so the exact bytes cannot be reproduced or checked here ("parity unpinned").
-This module writes the same LOGICAL content in the same order -- header fields as listed at
-db_builder.cpp:297-305, then one record per k-mer in filter order (:323-327) -- in a plain
-little-endian container of its own, and reads it back; a maintainer with i2l at hand swaps this one
-module for i2l's serializer.
-
-  magic   8s  b"IPKGPU1\\0"
-  header  u32 len + sequence_type ("DNA" | "AA")                     ipk_header.sequence_type
-          u64 n_index, n_index x { u32 num_nodes, f32 subtree_branch_length }   tree_index (db_builder.cpp:192-197)
-          u64 len + newick of the original tree                      tree
-          u64 kmer_size, f32 omega, u64 total_num_kmers, u64 total_num_entries
-  k-mers  per k-mer, in filter order: u32 key, f32 filter_value, u32 n, n x { u32 branch, f32 score }
+(ipk/src/db_builder.cpp:145-146,176-177,297-306,323-327).  The byte layout lives in ONE place,
+ipk_amd/csrc/ipk_format.hpp (a reconstruction: i2l and Boost are un-vendored, so it is not pinned against a real .ipk);
+it is written by ipkgpu_db_write (streamed from the device) and ipkgpu_db_write_host (host arrays: merged shards).
+This module calls the latter and parses the layout back for the tests.
 """
+import ctypes as C
 import struct
 
 import numpy as np
 
-MAGIC = b"IPKGPU1\0"
+from .engine import IpkGpuError, load_library
+
+ABI_SYMBOLS = ["ipkgpu_db_write", "ipkgpu_db_write_host", "ipkgpu_db_write_last_error", "ipkgpu_db_write_time_s"]
+_bound = False
 
 
-def write_db(path, sequence_type, tree_index, newick, kmer_size, omega, keys, key_offsets, branches, scores,
-             filter_values, order):
-    """keys/key_offsets/branches/scores: a database shard (ascending keys); order: positions in filter order."""
-    keys = np.asarray(keys, dtype=np.uint32)
-    off = np.asarray(key_offsets, dtype=np.int64)
-    order = np.asarray(order, dtype=np.int64)
-    n_keys, n_entries = len(keys), int(off[-1]) if len(off) else 0
-    lens = np.diff(off)[order]
-    # word layout of the record stream: [key, fv, n, (branch, score) * n] per k-mer
-    rec_words = 3 + 2 * lens
-    rec_start = np.concatenate([[0], np.cumsum(rec_words)[:-1]]) if n_keys else np.zeros(0, np.int64)
-    buf = np.empty(int(rec_words.sum()), dtype=np.uint32)
-    buf[rec_start] = keys[order]
-    buf[rec_start + 1] = np.asarray(filter_values, dtype=np.float32)[order].view(np.uint32)
-    buf[rec_start + 2] = lens.astype(np.uint32)
-    if n_entries:
-        src = np.repeat(off[:-1][order], lens) + (np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens))
-        dst = np.repeat(rec_start + 3, lens) + 2 * (np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens))
-        buf[dst] = np.asarray(branches, dtype=np.uint32)[src]
-        buf[dst + 1] = np.asarray(scores, dtype=np.float32).view(np.uint32)[src]
-    ti = np.zeros(len(tree_index), dtype=[("n", "<u4"), ("l", "<f4")])
-    for i, (n, l) in enumerate(tree_index):
-        ti[i] = (n, l)
-    with open(path, "wb") as fh:
-        fh.write(MAGIC)
-        st = sequence_type.encode()
-        fh.write(struct.pack("<I", len(st)) + st)
-        fh.write(struct.pack("<Q", len(ti)) + ti.tobytes())
-        nw = newick.encode()
-        fh.write(struct.pack("<Q", len(nw)) + nw)
-        fh.write(struct.pack("<QfQQ", kmer_size, omega, n_keys, n_entries))
-        fh.write(buf.astype("<u4").tobytes())
+class _Header(C.Structure):
+    _fields_ = [("sequence_type", C.c_char_p), ("tree_index_size", C.c_uint64), ("tree_num_nodes", C.POINTER(C.c_uint32)),
+                ("tree_subtree_length", C.POINTER(C.c_double)), ("newick", C.c_char_p), ("kmer_size", C.c_uint64),
+                ("omega", C.c_float)]
 
 
-def read_db(path):
-    """Returns (header dict, list of (key, filter_value, branches, scores) in file order)."""
-    raw = open(path, "rb").read()
-    assert raw[:8] == MAGIC, "not an ipk_amd database file"
-    p = 8
-    (n,) = struct.unpack_from("<I", raw, p); p += 4
-    st = raw[p:p + n].decode(); p += n
-    (ni,) = struct.unpack_from("<Q", raw, p); p += 8
-    ti = np.frombuffer(raw, dtype=[("n", "<u4"), ("l", "<f4")], count=ni, offset=p); p += ni * 8
-    (n,) = struct.unpack_from("<Q", raw, p); p += 8
-    newick = raw[p:p + n].decode(); p += n
-    k, omega, nk, ne = struct.unpack_from("<QfQQ", raw, p); p += struct.calcsize("<QfQQ")
-    words = np.frombuffer(raw, dtype="<u4", offset=p)
-    recs, q = [], 0
-    for _ in range(nk):
-        key, fvb, m = int(words[q]), words[q + 1:q + 2], int(words[q + 2])
-        body = words[q + 3:q + 3 + 2 * m].reshape(m, 2)
-        recs.append((key, float(fvb.view(np.float32)[0]), body[:, 0].copy(), body[:, 1].copy().view(np.float32)))
-        q += 3 + 2 * m
-    assert q == len(words)
-    hdr = dict(sequence_type=st, tree_index=[(int(a), float(b)) for a, b in ti], newick=newick, kmer_size=k,
-               omega=omega, total_num_kmers=nk, total_num_entries=ne)
+def _lib():
+    global _bound
+    L = load_library()
+    if not _bound:
+        L.ipkgpu_db_write.restype = C.c_int
+        L.ipkgpu_db_write.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Header), C.c_char_p, C.POINTER(C.c_uint64)]
+        L.ipkgpu_db_write_host.restype = C.c_int
+        L.ipkgpu_db_write_host.argtypes = [C.POINTER(_Header), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_char_p, C.POINTER(C.c_uint64)]
+        L.ipkgpu_db_write_last_error.restype = C.c_char_p
+        L.ipkgpu_db_write_last_error.argtypes = []
+        L.ipkgpu_db_write_time_s.restype = C.c_double
+        L.ipkgpu_db_write_time_s.argtypes = [C.c_void_p, C.c_int]
+        _bound = True
+    return L
+
+
+def _header(sequence_type, tree_index, newick, kmer_size, omega):
+    """tree_index: (num_nodes u32 [n], subtree_branch_length f64 [n]) or a list of (num_nodes, length) pairs."""
+    if isinstance(tree_index, tuple) and len(tree_index) == 2 and hasattr(tree_index[0], "dtype"):
+        nn, sl = tree_index
+    else:
+        nn = np.array([t[0] for t in tree_index], dtype=np.uint32)
+        sl = np.array([t[1] for t in tree_index], dtype=np.float64)
+    nn, sl = np.ascontiguousarray(nn, np.uint32), np.ascontiguousarray(sl, np.float64)
+    h = _Header(sequence_type.encode(), len(nn), nn.ctypes.data_as(C.POINTER(C.c_uint32)), sl.ctypes.data_as(C.POINTER(C.c_double)),
+                newick.encode(), int(kmer_size), float(omega))
+    h._keep = (nn, sl)
+    return h
+
+
+def write_db_device(engine, db, path, sequence_type, tree_index, newick, kmer_size, omega):
+    """ipkgpu_db_write: the shard `db` (filter values computed) streamed from device memory. Returns bytes written."""
+    L = _lib()
+    h = _header(sequence_type, tree_index, newick, kmer_size, omega)
+    n = C.c_uint64()
+    rc = L.ipkgpu_db_write(engine._h, db._h, C.byref(h), str(path).encode(), C.byref(n))
+    if rc != 0:
+        raise engine._err(rc)
+    return int(n.value)
+
+
+def write_times(engine):
+    L = _lib()
+    return {k: float(L.ipkgpu_db_write_time_s(engine._h, i)) for i, k in enumerate(("total_s", "device_s", "file_s"))}
+
+
+def write_db(path, sequence_type, tree_index, newick, kmer_size, omega, keys, key_offsets, branches, scores, filter_values, order):
+    """ipkgpu_db_write_host over host arrays: a database shard (ascending keys); order = positions in filter order."""
+    L = _lib()
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    off = np.ascontiguousarray(key_offsets, dtype=np.uint64)
+    ent = np.empty((len(branches), 2), dtype=np.uint32)
+    ent[:, 0] = np.asarray(branches, dtype=np.uint32)
+    ent[:, 1] = np.asarray(scores, dtype=np.float32).view(np.uint32)
+    fv = np.ascontiguousarray(filter_values, dtype=np.float32)
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    if len(off) == 0:
+        off = np.zeros(1, np.uint64)
+    h = _header(sequence_type, tree_index, newick, kmer_size, omega)
+    n = C.c_uint64()
+    rc = L.ipkgpu_db_write_host(C.byref(h), len(keys), keys.ctypes.data, off.ctypes.data, ent.ctypes.data, fv.ctypes.data,
+                                order.ctypes.data, str(path).encode(), C.byref(n))
+    if rc != 0:
+        raise IpkGpuError(rc, L.ipkgpu_db_write_last_error().decode())
+    return int(n.value)
+
+
+def read_db(path, as_arrays=False):
+    """Parses the layout of ipk_format.hpp.  Returns (header dict, records): records = list of (key, filter_value, branches,
+    scores) in file order, or with as_arrays the arrays (keys, filter_values, counts, entry_offsets, branches, scores)."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    buf = raw.tobytes()
+    p = 0
+
+    def take(fmt):
+        nonlocal p
+        v = struct.unpack_from("<" + fmt, buf, p)
+        p += struct.calcsize("<" + fmt)
+        return v[0] if len(v) == 1 else v
+
+    def take_string():
+        nonlocal p
+        n = take("Q")
+        s = buf[p:p + n].decode()
+        p += n
+        return s
+
+    assert take_string() == "serialization::archive", "not a Boost binary archive preamble"
+    lib_version = take("H")
+    sizes = take("BBBB")
+    assert sizes == (4, 8, 4, 8) and take("i") == 1
+    st = take_string()
+    ni = take("Q")
+    ti = np.frombuffer(buf, dtype=[("n", "<u8"), ("l", "<f8")], count=ni, offset=p)
+    p += ni * 16
+    newick = take_string()
+    k = take("Q"); omega = take("f"); nk = take("Q"); ne = take("Q")
+    hdr = dict(sequence_type=st, tree_index=[(int(a), float(b)) for a, b in ti], newick=newick, kmer_size=k, omega=omega,
+               total_num_kmers=nk, total_num_entries=ne, library_version=lib_version)
+    body = np.frombuffer(buf, dtype="<u4", offset=p) if (len(buf) - p) % 4 == 0 else None
+    assert body is not None and len(body) == 4 * nk + 2 * ne, "body size does not match the header's totals"
+    # record starts: head of 4 words, then 2 words per entry -- walk the counts
+    keys = np.empty(nk, np.uint32); fvs = np.empty(nk, np.float32); counts = np.empty(nk, np.uint64)
+    starts = np.empty(nk, np.int64)
+    q = 0
+    for i in range(nk):
+        starts[i] = q
+        c = int(body[q + 2]) | (int(body[q + 3]) << 32)
+        counts[i] = c
+        q += 4 + 2 * c
+    assert q == len(body)
+    keys[:] = body[starts]; fvs[:] = body[starts + 1].view(np.float32)
+    eoff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    mask = np.ones(len(body), bool)
+    for d in range(4):
+        mask[starts + d] = False
+    ent = body[mask].reshape(-1, 2)
+    br, sc = ent[:, 0].copy(), ent[:, 1].copy().view(np.float32)
+    if as_arrays:
+        return hdr, (keys, fvs, counts, eoff, br, sc)
+    recs = [(int(keys[i]), float(fvs[i]), br[eoff[i]:eoff[i + 1]], sc[eoff[i]:eoff[i + 1]]) for i in range(nk)]
     return hdr, recs
 
 

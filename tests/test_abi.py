@@ -23,8 +23,8 @@ def test_header_symbols_exported():
     assert declared, "header parse failed"
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ipkgpu.h but not exported"
-    from ipk_amd import loader
-    assert sorted(E.ABI_SYMBOLS + loader.ABI_SYMBOLS) == declared
+    from ipk_amd import dbfile, loader, tree
+    assert sorted(E.ABI_SYMBOLS + loader.ABI_SYMBOLS + tree.ABI_SYMBOLS + dbfile.ABI_SYMBOLS) == declared
 
 
 def test_host_helpers_no_gpu_needed():
