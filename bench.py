@@ -7,8 +7,14 @@ phylo-k-mer database (what `_phylo_kmer_db` holds after explore_kmers, db_builde
 N > 1 ranks the database is sharded by k-mer owner and the step includes the all-to-all exchange
 (RCCL) and merge.  `--output group` times the group-major form (sorted (key, score) set per branch).  Default workload: BASELINE.json configs[1]
 ("Synthetic DNA: 2000 extended nodes x 10000 sites, k=10, omega=1.5, 1xMI355X").
-Branch groups shard across ranks with no data-path collective -> weak scaling (every rank scores
-its own 1000 groups).
+Scaling: `--scaling strong` (default; the north star's fixed 2000-node workload): the config's branch groups are split
+over the ranks by contiguous ranges (distributed.shard_range), value = the whole workload's scored phylo-k-mers per
+second.  `--scaling weak`: every rank scores its own full copy of the config (per-GPU work fixed).  Either way the only
+collective is the k-mer-keyed exchange of the database parts.
+
+`e2e` in the JSON line (rank 0, N = 1): the COLD build of the same workload, wall clock -- new context, matrices uploaded
+from host memory, first scoring call, MIF0 filter, database file written -- i.e. what a one-shot `ipk.py build` pays
+beyond reading its inputs; never part of `value`.
 """
 import argparse
 import json
@@ -24,6 +30,46 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def cold_end_to_end(eng_warm, cfg, d_logp, groups, eps, device):
+    """Cold build of the benchmarked workload on one GPU, wall clock: what `ipk.py build` pays after its inputs are parsed.
+    The reference prints the same stages (Computation / Filtering / Merge time, db_builder.cpp:217,230-236,288-290,334-336).
+    The warm context is closed first so the new one allocates everything again."""
+    import shutil
+    import tempfile
+    import torch
+    import ipk_amd
+    from ipk_amd import dbfile
+    sigma, k = cfg["sigma"], cfg["k"]
+    host = d_logp.cpu().numpy()                                   # the matrices as the loader leaves them: pageable host memory
+    n_groups = len(np.unique(groups))
+    eng_warm.close()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    tmpdir = tempfile.mkdtemp(prefix="ipk_e2e_")
+    path = os.path.join(tmpdir, "DB.ipk")
+    res = {}
+    try:
+        t_all = time.perf_counter()
+        t0 = time.perf_counter(); eng = ipk_amd.Engine(device); res["create_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); dev = torch.from_numpy(host).cuda(); torch.cuda.synchronize(); res["upload_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); parts = eng.score_groups_keymajor(dev, groups, k, eps, n_owners=1); res["score_first_call_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); db = eng.db_from_parts(parts, sigma, k); res["db_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); db.filter_mif0(eng, n_groups + 1, ipk_amd.score_threshold(cfg["omega"], sigma, k)); res["filter_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        nbytes = dbfile.write_db_device(eng, db, path, "DNA" if sigma == 4 else "AA", [], "", k, cfg["omega"])
+        res["write_s"] = time.perf_counter() - t0
+        wt = dbfile.write_times(eng)
+        res["write_device_s"], res["write_file_s"] = wt["device_s"], wt["file_s"]
+        res["cold_s"] = time.perf_counter() - t_all
+        res["gpu_part_s"] = res["create_s"] + res["upload_s"] + res["score_first_call_s"] + res["db_s"] + res["filter_s"] + res["write_device_s"]
+        res["file_bytes"] = nbytes
+        res["file_on"] = tmpdir
+        res["kmers"], res["entries"], res["scored"] = db.num_keys, db.num_entries, parts.emitted
+        db.free(); parts.free(); eng.close()
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -35,6 +81,8 @@ def main():
     ap.add_argument("--output", default="db", choices=["db", "group"], help="db: key-major database shard; group: per-branch CSR")
     ap.add_argument("--cpu-groups", type=int, default=-1, help="groups timed on the CPU oracle (-1 = auto, 0 = skip)")
     ap.add_argument("--variant", type=int, default=0, help="engine option 'variant' (0 = auto; diagnostics: 1 atomics, 2 chunked pool, 3 exact partition)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="strong: the config's groups split over the ranks; weak: a full copy per rank")
+    ap.add_argument("--e2e", type=int, default=1, help="1: also time the cold end-to-end build (N = 1 only); 0: skip")
     args = ap.parse_args()
 
     import torch
@@ -67,18 +115,26 @@ def main():
     if args.alpha:
         cfg["alpha"] = args.alpha
     ng, mpg, sites, sigma, k = cfg["n_groups"], cfg["mats_per_group"], cfg["sites"], cfg["sigma"], cfg["k"]
-    n_mats = ng * mpg
     eps = ipk_amd.log_threshold(cfg["omega"], sigma, k)
+    from ipk_amd import distributed as D
+    ng_total = ng if args.scaling == "strong" else ng * world
+    if args.scaling == "strong":
+        g_lo, g_hi = D.shard_range(ng, world, rank)           # this rank's contiguous range of the config's groups
+    else:
+        g_lo, g_hi = rank * ng, (rank + 1) * ng               # its own copy: groups [rank * ng, (rank + 1) * ng) of an N-fold workload
+    ng = g_hi - g_lo
+    n_mats = ng * mpg
+    first_mat_of_rank = g_lo * mpg
 
-    # synthetic matrices of this rank (weak scaling: rank r owns matrices [r*n_mats, (r+1)*n_mats))
+    # synthetic matrices of this rank
     t0 = time.time()
     d_logp = torch.empty((n_mats, sites, sigma), dtype=torch.float32, device="cuda")
     step_m = max(1, min(n_mats, (64 << 20) // (sites * sigma * 4)))
     for m0 in range(0, n_mats, step_m):
         m1 = min(n_mats, m0 + step_m)
         d_logp[m0:m1].copy_(torch.from_numpy(synth_matrices(m1 - m0, sites, sigma, cfg["alpha"], cfg["seed"],
-                                                            first_mat=rank * n_mats + m0)))
-    groups = np.repeat(np.arange(ng, dtype=np.uint32), mpg)
+                                                            first_mat=first_mat_of_rank + m0)))
+    groups = np.repeat(np.arange(g_lo, g_hi, dtype=np.uint32), mpg)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
@@ -95,8 +151,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from ipk_amd import distributed as D
-    acc = {"score": 0.0, "launches": 0.0, "total": 0.0, "compact": 0.0, "prefix": 0.0, "merge": 0.0, "main": 0.0, "reduce": 0.0}
+    acc = {"score": 0.0, "launches": 0.0, "total": 0.0, "compact": 0.0, "prefix": 0.0, "merge": 0.0, "main": 0.0, "reduce": 0.0, "exchange_exposed": 0.0}
     emitted = entries = n_keys = 0
 
     def step(record):
@@ -110,6 +165,7 @@ def main():
             emitted, entries, n_keys = t.emitted, db.num_entries, db.num_keys
             if record:
                 acc["merge"] += db.time_ms()
+                acc["exchange_exposed"] += getattr(t, "exchange_exposed_ms", 0.0)
             db.free()
         if record:
             acc["score"] += t.time_ms(E.T_SCORE); acc["launches"] += t.time_ms(E.T_SCORE_LAUNCHES)
@@ -131,7 +187,12 @@ def main():
     barrier()
     score_ms, launches, total_ms, compact_ms, prefix_ms = acc["score"], acc["launches"], acc["total"], acc["compact"], acc["prefix"]
     elapsed = time.perf_counter() - t_start
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
+        tl = torch.zeros(world, dtype=torch.float64, device="cuda")
+        tl[rank] = acc["total"] / args.steps                       # device time of this rank's scoring calls per step
+        dist.all_reduce(tl)
+        rank_ms = [float(x) for x in tl.tolist()]
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -169,10 +230,10 @@ def main():
         out = {
             "metric": "scored phylo-k-mers/sec", "value": value, "unit": "phylo-k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: synthetic {'DNA' if sigma == 4 else 'AA'} {n_mats} extended nodes "
                                    f"({ng} branch groups x {mpg}) x {sites} sites, k={k}, omega={cfg['omega']}, "
-                                   f"alpha={cfg['alpha']}, per GPU",
+                                   f"alpha={cfg['alpha']}, per GPU" + (f"; whole workload {ng_total} branch groups" if world > 1 else ""),
                        "scored_per_step_per_gpu": emitted, "branch_kmer_entries_per_gpu": entries,
                        "output": "key-major database shard" if args.output == "db" else "group-major CSR",
                        "sharding": f"branch groups over {world} rank(s)" + ("; k-mer-keyed all-to-all (RCCL) + merge" if world > 1 and args.output == "db" else "; no collective")},
@@ -184,9 +245,16 @@ def main():
             "phases_ms_per_step": {"prefix": prefix_ms / args.steps, "score": score_ms / args.steps,
                                    "score_main_kernel": acc["main"] / args.steps, "score_lds_reduce": acc["reduce"] / args.steps,
                                    "compact": compact_ms / args.steps, "device_total": total_ms / args.steps,
-                                   "db_merge": acc["merge"] / args.steps},
+                                   "db_merge": acc["merge"] / args.steps,
+                                   "exchange_exposed": acc["exchange_exposed"] / args.steps,
+                                   "per_rank_device_total": rank_ms},
             "setup_s": {"synth_and_upload": t_gen, "engine_init_first_call": t_init},
         }
+        if world == 1 and args.e2e:
+            try:
+                out["e2e"] = cold_end_to_end(eng, cfg, d_logp, groups, eps, local_rank)
+            except Exception as exc:                              # e.g. no room for the file: the steady-state line stays valid
+                out["e2e"] = {"error": repr(exc)}
         # CPU baseline: the oracle (C restatement), 1 thread, bounded sample of the same workload
         n_cpu = args.cpu_groups
         if world == 1 and n_cpu != 0:
@@ -200,6 +268,8 @@ def main():
             sample = synth_matrices(n_cpu * mpg, sites, sigma, cfg["alpha"], cfg["seed"], first_mat=0)
             tc = time.perf_counter(); e_cpu, u_cpu = co.explore_many(sample, mpg, k, eps); tc = time.perf_counter() - tc
             # the same sample through the GPU path: scored count and unique (branch, k-mer) entries must agree
+            if not eng._h:
+                eng = ipk_amd.Engine(local_rank)                 # (the cold end-to-end leg closed the benchmark's context)
             rs = eng.score_groups(sample, np.repeat(np.arange(n_cpu, dtype=np.uint32), mpg), k, eps)
             out["sample_check"] = {"scored_equal": rs.emitted == e_cpu, "entries_equal": rs.num_entries == u_cpu,
                                    "scored": e_cpu, "entries": u_cpu}

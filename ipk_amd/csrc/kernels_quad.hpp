@@ -154,25 +154,12 @@ __device__ __forceinline__ uint32_t to_sgpr(uint32_t x)
     return r;
 }
 
-// The pair pool as a structured buffer: record = one chunk (CH pairs = 2 KiB), so that the hardware forms
-// base + chunk * 2048 + byte_offset (buffer_store ... idxen offen) and the 64-bit address arithmetic -- four VALU instructions
-// per store -- disappears.  Range check: chunk < num_records = pool_cap + 1 (the spare chunk included).
-typedef int quad_v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ quad_v4i pool_rsrc(const uint2* pool, uint32_t pool_cap)
+// A pool store.  (A structured-buffer form -- buffer_store ... idxen offen with one record per chunk, which would leave the
+// 64-bit address arithmetic to the hardware -- was tried and is WRONG here: the buffer unit forms index * stride + offset in
+// 32 bits, so chunks past 4 GiB wrap around.  The pool is tens of GB.)
+__device__ __forceinline__ void pool_store(uint2* pool, uint32_t chunk, uint32_t slot, uint2 val)
 {
-    const unsigned long long b = (unsigned long long)pool;
-    quad_v4i r;
-    r.x = (int)(uint32_t)b;
-    r.y = (int)(((uint32_t)(b >> 32) & 0xFFFFu) | ((CH * 8u) << 16));       // base[47:32], stride = 2048, no swizzle
-    r.z = (int)(pool_cap + 1u);
-    r.w = 0x00020000;
-    return r;
-}
-__device__ __forceinline__ void pool_store(const quad_v4i& rsrc, uint32_t chunk, uint32_t slot, uint2 val)
-{
-    const unsigned long long addr = ((unsigned long long)(slot * 8u) << 32) | (unsigned long long)chunk;   // {index, offset}
-    const unsigned long long data = ((unsigned long long)val.y << 32) | (unsigned long long)val.x;
-    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 idxen offen" : : "v"(data), "v"(addr), "s"(rsrc) : "memory");
+    pool[(size_t)chunk * CH + slot] = val;
 }
 
 // floor(x / n) for 0 <= x < 128, 1 <= n <= 64, with rn = 1 / n to within a few ulp: (x + 0.5) / n is at least 1 / 128 away from every
@@ -268,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
     const float lane_h = (float)lane + 0.5f;
     const float eps = p.eps;
     const bool st_ok = !(p.flags & 1u);
-    const quad_v4i rsrc = pool_rsrc(p.pool, p.pool_cap);
+    const bool count_only = (p.flags & 2u) != 0;     // count the scored pairs only: nothing is reserved or stored
     // per step: the node this lane's slot evaluates
     uint32_t st_j4[Q::NSTEPS], st_th[Q::NSTEPS], st_off[Q::NSTEPS], st_cmul[Q::NSTEPS], st_code[Q::NSTEPS];
     bool st_on[Q::NSTEPS];
@@ -420,6 +407,11 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                             any |= m[u];
                         }
                         if (any == 0) return;
+                        if (count_only) {                                             // flag 2: the pool-sizing pre-pass
+#pragma unroll
+                            for (int u = 0; u < NS; ++u) emitted += (uint32_t)__popcll(m[u]);
+                            return;
+                        }
                         uint32_t rank[NS], bk[NS]; unsigned long long got[NS];
 #pragma unroll
                         for (int u = 0; u < NS; ++u) {
@@ -438,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                             v[u] = fill + rank[u];
                             val[u] = make_uint2(a[u].x + b.x, __float_as_uint(s[u]));
                             const bool in = v[u] < CH;
-                            if (pass[u] && in) { if (st_ok) pool_store(rsrc, cb, v[u], val[u]); }
+                            if (pass[u] && in) { if (st_ok) pool_store(p.pool, cb, v[u], val[u]); }
                             const bool oc = v[u] >= CH;
                             over[u] = pass[u] && oc;
                             ovf[u] = m[u] & ballot64(oc);
@@ -455,7 +447,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
 #pragma unroll
                             for (int u = 0; u < NS; ++u) {
                                 const bool h = over[u] && bk[u] == bb;
-                                if (h) { if (st_ok) pool_store(rsrc, nid, v[u] - CH, val[u]); }
+                                if (h) { if (st_ok) pool_store(p.pool, nid, v[u] - CH, val[u]); }
                                 ovf[u] &= ~ballot64(h);
                                 anyo |= ovf[u];
                             }
@@ -470,8 +462,8 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
             }
         }
     }
-    app.close();
-    if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);       // (diagnostic flag 4 only: the pairs are counted from the chunk descriptors)
+    if (!count_only) app.close();
+    if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);       // (flags 2 / 4 only: otherwise the pairs are counted from the chunk descriptors)
 }
 
 }  // namespace ipkgpu

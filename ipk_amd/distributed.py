@@ -134,10 +134,13 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
         pj = engine.score_groups_keymajor(logp[cuts[j]:cuts[j + 1]], mat_group[cuts[j]:cuts[j + 1]], k, log_eps, n_owners=world)
         scored.append(pj)
         xs.append(exchange(pj))                                          # in flight while the next piece is scored
+    import time
+    t_wait = time.perf_counter()
     for x in xs:
         for w in x["works"]:
             w.wait()
     torch.cuda.current_stream().synchronize()
+    scored[0].exchange_exposed_ms = (time.perf_counter() - t_wait) * 1e3     # what the overlap with scoring did not hide
     # sources in global group order: (rank r, piece 0), (rank r, piece 1), ...
     counts = torch.stack([x["rcounts"] for x in xs], dim=1).reshape(n * world, -1).contiguous()
     # all receive buffers are addressed from the lowest base pointer among them (entries are 8 bytes)

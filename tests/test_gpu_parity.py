@@ -298,3 +298,31 @@ def test_randomised_small_cases(engine):
                 db.free()
             parts.free()
     engine.set_option("variant", 0)
+
+
+def test_large_pair_pool_matches_small_batches(engine):
+    """A pair pool beyond 4 GiB (32-bit byte offsets wrap there): 300 branch groups of 10 000-site matrices in ONE batch
+    against the same groups scored 25 at a time -- every group's (key, score) set must be identical."""
+    n_groups, sites, k = 300, 10000, 10
+    mats = synth_matrices(n_groups * 2, sites, 4, 0.05, 4242)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32), 2)
+    eps = co.log_threshold(1.5, 4, k)
+    big = engine.score_groups(mats, groups, k, eps)
+    offsets = big.offsets.copy()
+    bk, bs = big.keys().copy(), big.scores().copy()
+    emitted = big.emitted
+    big.free()
+    assert emitted * 8 > 5 << 30, "workload too small to put the pool beyond 4 GiB"
+    tot = 0
+    for g0 in range(0, n_groups, 25):
+        r = engine.score_groups(mats[2 * g0:2 * g0 + 50], groups[2 * g0:2 * g0 + 50], k, eps)
+        tot += r.emitted
+        a, b = int(offsets[g0]), int(offsets[g0 + 25])
+        assert np.array_equal(r.offsets, offsets[g0:g0 + 26] - offsets[g0])
+        assert np.array_equal(r.keys(), bk[a:b]) and np.array_equal(r.scores().view(np.uint32), bs[a:b].view(np.uint32))
+        r.free()
+    assert tot == emitted
+    # and one group of the big batch against the oracle
+    keys, scores, _ = co.explore_group(mats[2 * 137:2 * 137 + 2], k, eps)
+    a, b = int(offsets[137]), int(offsets[138])
+    assert np.array_equal(bk[a:b], keys) and np.array_equal(bs[a:b].view(np.uint32), scores.view(np.uint32))
