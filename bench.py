@@ -50,7 +50,8 @@ def cold_end_to_end(eng_warm, cfg, d_logp, groups, eps, device):
     try:
         t_all = time.perf_counter()
         t0 = time.perf_counter(); eng = ipk_amd.Engine(device); res["create_s"] = time.perf_counter() - t0
-        t0 = time.perf_counter(); dev = torch.from_numpy(host).cuda(); torch.cuda.synchronize(); res["upload_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); dev = torch.empty(host.shape, dtype=torch.float32, device="cuda"); torch.cuda.synchronize(); res["alloc_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); dev.copy_(torch.from_numpy(host)); torch.cuda.synchronize(); res["upload_s"] = time.perf_counter() - t0
         t0 = time.perf_counter(); parts = eng.score_groups_keymajor(dev, groups, k, eps, n_owners=1); res["score_first_call_s"] = time.perf_counter() - t0
         t0 = time.perf_counter(); db = eng.db_from_parts(parts, sigma, k); res["db_s"] = time.perf_counter() - t0
         t0 = time.perf_counter(); db.filter_mif0(eng, n_groups + 1, ipk_amd.score_threshold(cfg["omega"], sigma, k)); res["filter_s"] = time.perf_counter() - t0
@@ -60,7 +61,7 @@ def cold_end_to_end(eng_warm, cfg, d_logp, groups, eps, device):
         wt = dbfile.write_times(eng)
         res["write_device_s"], res["write_file_s"] = wt["device_s"], wt["file_s"]
         res["cold_s"] = time.perf_counter() - t_all
-        res["gpu_part_s"] = res["create_s"] + res["upload_s"] + res["score_first_call_s"] + res["db_s"] + res["filter_s"] + res["write_device_s"]
+        res["gpu_part_s"] = res["create_s"] + res["alloc_s"] + res["upload_s"] + res["score_first_call_s"] + res["db_s"] + res["filter_s"] + res["write_device_s"]
         res["file_bytes"] = nbytes
         res["file_on"] = tmpdir
         res["kmers"], res["entries"], res["scored"] = db.num_keys, db.num_entries, parts.emitted

@@ -199,6 +199,30 @@ void ipkgpu_parts_free(ipkgpu_parts* p);
 int ipkgpu_merge_parts(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, uint32_t n_owners,
                        uint32_t n_sources, const uint32_t* counts_dev, const void* entries_dev,
                        const uint64_t* source_offsets, ipkgpu_db** out);
+/* Like ipkgpu_merge_parts, with one pointer pair per source instead of one base and offsets: counts_dev[s] = the source's
+ * counts row [slots] (device), entries_dev[s] = its entry block (device).  Both pointer arrays live in HOST memory. */
+int ipkgpu_merge_parts_ptrs(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, uint32_t n_owners, uint32_t n_sources,
+                            const uint32_t* const* counts_dev, const void* const* entries_dev, ipkgpu_db** out);
+
+/* ---- the exchange step itself: RCCL over xGMI, inside the library ------------------------------------------------
+ * One process per GPU.  Rank 0 draws an id (ipkgpu_comm_unique_id) and hands its 128 bytes to the other ranks by any means
+ * (MPI, a file, torch.distributed); every rank then calls ipkgpu_comm_init.  Per range ("piece") of its branch groups a rank
+ * calls ipkgpu_score_groups_keymajor_device(..., n_owners = world) and ipkgpu_exchange_begin, which enqueues block o -> rank o
+ * (grouped ncclSend/ncclRecv on the communicator's own stream) and returns, so the transfer runs under the next piece's
+ * scoring; ipkgpu_exchange_merge waits for the pieces and merges (rank, piece)-ordered sources into this rank's shard.
+ * All ranks must use the same number of pieces.  RCCL is loaded at run time: IPKGPU_ERR_NODEVICE if it is not there.
+ * CPU analogue: branch_group.cpp:45-70,104-107 (merge_batch, kmer_batch), db_builder.cpp:392-458 (merge_stage2). */
+typedef struct ipkgpu_xfer ipkgpu_xfer;
+int ipkgpu_comm_unique_id(uint8_t* id128);
+int ipkgpu_comm_init(ipkgpu_ctx* ctx, const uint8_t* id128, int rank, int world);
+int ipkgpu_comm_rank(const ipkgpu_ctx* ctx);
+int ipkgpu_comm_world(const ipkgpu_ctx* ctx);
+int ipkgpu_exchange_begin(ipkgpu_ctx* ctx, ipkgpu_parts* parts, ipkgpu_xfer** out);     /* parts stay alive until the merge */
+int ipkgpu_exchange_merge(ipkgpu_ctx* ctx, ipkgpu_xfer* const* xfers, uint32_t n_pieces, uint32_t sigma, uint32_t k, ipkgpu_db** out,
+                          double* exposed_ms /* optional: time spent waiting for transfers */);
+double ipkgpu_xfer_exposed_ms(const ipkgpu_xfer* x);
+void ipkgpu_xfer_free(ipkgpu_xfer* x);
+
 /* Single-GPU shortcut (n_owners == 1): the parts already ARE the database; produces the key list and
  * MOVES the entry array out of `parts` (which stays valid for its counts/timings, entries become NULL). */
 int ipkgpu_db_from_parts(ipkgpu_ctx* ctx, ipkgpu_parts* parts, uint32_t sigma, uint32_t k, ipkgpu_db** out);

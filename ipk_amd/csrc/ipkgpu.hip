@@ -55,8 +55,12 @@ struct DevBuf {                       // grow-only device workspace
 
 }  // namespace
 
+struct ipkgpu_comm;
+struct ipkgpu_ctx;
+static void ipkgpu_comm_release(ipkgpu_ctx* ctx);
 struct ipkgpu_ctx {
     int device = 0;
+    ipkgpu_comm* comm = nullptr;      // RCCL communicator of the k-mer-keyed exchange (comm_rccl.hpp), if initialised
     hipStream_t stream = nullptr;
     std::string err;
     int64_t workspace_bytes = 0;
@@ -65,6 +69,7 @@ struct ipkgpu_ctx {
     int64_t opt_pool_chunks = 0;      // test knob: size of the FIRST pair-pool attempt (forces the grow-and-redo path)
     DevBuf table, best, ovfq, counts, offsets, goff, idx, branch, scan_sums, scan_boff, tmp_a, tmp_b, tmp_c;
     DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
+    DevBuf ptrs;                 // per-source pointer arrays of a merge
     DevBuf mask;                 // occupancy bits of ctx->table ([groups in batch][mask_words]) when mask_valid
     bool mask_valid = false;
     uint64_t mask_words = 0;     // 2 * ceil(table_size / 64): rows padded to whole 64-slot blocks
@@ -284,9 +289,10 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
                       &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
                       &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->mask,
-                      &ctx->rank, &ctx->ucnt};
+                      &ctx->rank, &ctx->ucnt, &ctx->ptrs};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
+    ipkgpu_comm_release(ctx);
     if (ctx->small) (void)hipFree(ctx->small);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1536,41 +1542,39 @@ void ipkgpu_result_free(ipkgpu_result* r)
 // ---- key-major output: database parts and their merge ----------------------------------------------
 namespace {
 
-// Merges S sources of one owner: counts [S][slots] (contiguous), entries of source s start at
-// src + src_base[s].  Writes dst entries (n_total), dst_off [slots+1] into ctx->tmp_b, and, when
-// `db` is given, the compact key list.
+// Merges S sources of one owner: source s brings its counts row counts_rows[s] ([slots], device) and its entry block
+// src_rows[s] (device).  Writes dst entries (n_total), dst_off [slots+1] into ctx->tmp_b, and, when `db` is given, the
+// compact key list.
 int merge_sources(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, uint32_t P, uint32_t S, uint64_t slots,
-                  const uint32_t* counts, const uint2* src, const std::vector<uint64_t>& src_base,
+                  const std::vector<const uint32_t*>& counts_rows, const std::vector<const uint2*>& src_rows,
                   uint32_t* total_out /*[slots] device*/, uint2** dst_out, uint64_t* n_total_out, ipkgpu_db* db)
 {
-    // workspaces: tmp_a = flags u32[slots] ; tmp_b = dst_off u64[slots+1] ; tmp_c = src_off u64[S][slots+1]
+    // workspaces: tmp_a = flags u32[slots] ; tmp_b = dst_off u64[slots+1] ; tmp_c = src_off u64[S][slots+1] ; goff = the pointer arrays
     RC_TRY(ensure(ctx, ctx->tmp_a, slots * 4));
     RC_TRY(ensure(ctx, ctx->tmp_b, (slots + 1) * 8));
     RC_TRY(ensure(ctx, ctx->tmp_c, (size_t)S * (slots + 1) * 8));
+    RC_TRY(ensure(ctx, ctx->ptrs, (size_t)S * 16));
+    std::vector<const void*> hp((size_t)2 * S);
+    for (uint32_t s = 0; s < S; ++s) { hp[s] = counts_rows[s]; hp[S + s] = src_rows[s]; }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ptrs.p, hp.data(), hp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                 // hp is a stack-lifetime pageable buffer
+    const uint32_t* const* d_counts = ctx->ptrs.as<const uint32_t*>();
+    const uint2* const* d_src = reinterpret_cast<const uint2* const*>(ctx->ptrs.as<const void*>() + S);
     const uint32_t nb256 = (uint32_t)((slots + 255) / 256);
-    hipLaunchKernelGGL(merge_sum_counts_kernel, dim3(nb256), dim3(256), 0, ctx->stream, counts, S, slots, total_out,
+    hipLaunchKernelGGL(merge_sum_counts_kernel, dim3(nb256), dim3(256), 0, ctx->stream, d_counts, S, slots, total_out,
                        ctx->tmp_a.as<uint32_t>());
     HIP_TRY(ctx, hipGetLastError());
     RC_TRY(scan_u32(ctx, total_out, slots, ctx->tmp_b.as<uint64_t>()));
     for (uint32_t s = 0; s < S; ++s)
-        RC_TRY(scan_u32(ctx, counts + (size_t)s * slots, slots, ctx->tmp_c.as<uint64_t>() + (size_t)s * (slots + 1)));
+        RC_TRY(scan_u32(ctx, counts_rows[s], slots, ctx->tmp_c.as<uint64_t>() + (size_t)s * (slots + 1)));
     uint64_t n_total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&n_total, ctx->tmp_b.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // per-source scans are relative to the source's own start: add the bases on the host side by
-    // passing adjusted source pointers is not possible for one `src`, so fold the base into the scan
-    // output with a tiny kernel-free trick: the copy kernel takes src_off relative to `src`; we add
-    // src_base[s] to source s's whole offset row here.
-    for (uint32_t s = 0; s < S; ++s) {
-        if (src_base[s] == 0) continue;
-        hipLaunchKernelGGL(add_base_kernel, dim3((uint32_t)((slots + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ctx->tmp_c.as<uint64_t>() + (size_t)s * (slots + 1), slots + 1, src_base[s]);
-    }
     uint2* dst = nullptr;
     HIP_TRY(ctx, ctx_alloc(ctx, (void**)&dst, std::max<uint64_t>(n_total, 1) * 8));
     if (slots) {
-        hipLaunchKernelGGL(merge_copy_kernel, dim3((uint32_t)((slots + 3) / 4)), dim3(256), 0, ctx->stream, counts, S, slots,
-                           ctx->tmp_c.as<uint64_t>(), src, ctx->tmp_b.as<uint64_t>(), dst);
+        hipLaunchKernelGGL(merge_copy_kernel, dim3((uint32_t)((slots + 3) / 4)), dim3(256), 0, ctx->stream, d_counts, S, slots,
+                           ctx->tmp_c.as<uint64_t>(), d_src, ctx->tmp_b.as<uint64_t>(), dst);
     }
     *dst_out = dst;                       // owned by the caller from here on (also on failure)
     *n_total_out = n_total;
@@ -1609,6 +1613,23 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     if (!out) return fail(ctx, IPKGPU_ERR_INVALID, "null out pointer");
     *out = nullptr;
     if (n_owners == 0) return fail(ctx, IPKGPU_ERR_INVALID, "n_owners must be >= 1");
+    if (n_mats == 0) {
+        // a rank without branch groups (more ranks than groups): empty parts, so that it still takes part in the exchange
+        if ((sigma != 4 && sigma != 20) || k < 2 || k > ipkgpu_max_k(sigma)) return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        ipkgpu_parts* e = new (std::nothrow) ipkgpu_parts();
+        if (!e) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
+        e->ctx = ctx; e->n_owners = n_owners; e->slots = (ipow(sigma, (int)k) + n_owners - 1) / n_owners;
+        e->owner_off.assign((size_t)n_owners + 1, 0);
+        struct EGuard { ipkgpu_parts* r; ~EGuard() { if (r) ipkgpu_parts_free(r); } } eg{e};
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&e->d_counts, (size_t)n_owners * e->slots * 4));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&e->d_entries, 8));
+        HIP_TRY(ctx, hipMemsetAsync(e->d_counts, 0, (size_t)n_owners * e->slots * 4, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        eg.r = nullptr;
+        *out = e;
+        return IPKGPU_OK;
+    }
     Plan pl;
     RC_TRY(make_plan(ctx, logp_dev, n_mats, sites, sigma, mat_group, k, log_eps, pl));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1699,32 +1720,21 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         uint64_t grand = 0;
         for (auto& b : batches) grand += b.owner_off[P];
         HIP_TRY(ctx, ctx_alloc(ctx, (void**)&parts->d_entries, std::max<uint64_t>(grand, 1) * 8));
-        uint32_t* cnt_rows = nullptr;      // [S][slots] of the current owner
-        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&cnt_rows, (size_t)S * slots * 4));
-        uint2* src_cat = nullptr;          // sources of the current owner, concatenated
         uint64_t done = 0;
         int rc = IPKGPU_OK;
         for (uint32_t o = 0; o < P && rc == IPKGPU_OK; ++o) {
-            std::vector<uint64_t> base(S);
-            uint64_t n_o = 0;
-            for (uint32_t s = 0; s < S; ++s) { base[s] = n_o; n_o += batches[s].owner_off[o + 1] - batches[s].owner_off[o]; }
-            if (ctx_alloc(ctx, (void**)&src_cat, std::max<uint64_t>(n_o, 1) * 8) != hipSuccess) { rc = fail(ctx, IPKGPU_ERR_NOMEM, "out of device memory in batch merge"); break; }
-            for (uint32_t s = 0; s < S; ++s) {
-                (void)hipMemcpyAsync(cnt_rows + (size_t)s * slots, batches[s].counts + (size_t)o * slots, slots * 4, hipMemcpyDeviceToDevice, ctx->stream);
-                const uint64_t n_s = batches[s].owner_off[o + 1] - batches[s].owner_off[o];
-                if (n_s) (void)hipMemcpyAsync(src_cat + base[s], batches[s].entries + batches[s].owner_off[o], n_s * 8, hipMemcpyDeviceToDevice, ctx->stream);
-            }
+            std::vector<const uint32_t*> crow(S);
+            std::vector<const uint2*> srow(S);
+            for (uint32_t s = 0; s < S; ++s) { crow[s] = batches[s].counts + (size_t)o * slots; srow[s] = batches[s].entries + batches[s].owner_off[o]; }
             uint2* dst = nullptr; uint64_t n_total = 0;
-            rc = merge_sources(ctx, sigma, k, o, P, S, slots, cnt_rows, src_cat, base, parts->d_counts + (size_t)o * slots, &dst, &n_total, nullptr);
+            rc = merge_sources(ctx, sigma, k, o, P, S, slots, crow, srow, parts->d_counts + (size_t)o * slots, &dst, &n_total, nullptr);
             if (rc == IPKGPU_OK) {
                 if (n_total) (void)hipMemcpyAsync(parts->d_entries + done, dst, n_total * 8, hipMemcpyDeviceToDevice, ctx->stream);
                 (void)hipStreamSynchronize(ctx->stream);
                 parts->owner_off[o] = done; done += n_total; parts->owner_off[o + 1] = done;
             }
             ctx_release(ctx, dst);
-            ctx_release(ctx, src_cat); src_cat = nullptr;
         }
-        ctx_release(ctx, cnt_rows);
         if (rc) return rc;
         ev_compact.push_back({m0, sw.mark()});
     }
@@ -1785,10 +1795,45 @@ int ipkgpu_merge_parts(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t own
     struct Guard { ipkgpu_db* r; ~Guard() { if (r) ipkgpu_db_free(r); } } guard{db};
     Stopwatch sw(ctx->stream);
     const int t0 = sw.mark();
-    std::vector<uint64_t> base(source_offsets, source_offsets + n_sources);
+    std::vector<const uint32_t*> crow(n_sources);
+    std::vector<const uint2*> srow(n_sources);
+    for (uint32_t s = 0; s < n_sources; ++s) {
+        crow[s] = counts_dev + (size_t)s * slots;
+        srow[s] = reinterpret_cast<const uint2*>(entries_dev) + source_offsets[s];
+    }
     RC_TRY(ensure(ctx, ctx->counts, slots * 4));
-    RC_TRY(merge_sources(ctx, sigma, k, owner, n_owners, n_sources, slots, counts_dev, reinterpret_cast<const uint2*>(entries_dev),
-                         base, ctx->counts.as<uint32_t>(), &db->d_entries, &db->n_entries, db));
+    RC_TRY(merge_sources(ctx, sigma, k, owner, n_owners, n_sources, slots, crow, srow, ctx->counts.as<uint32_t>(), &db->d_entries, &db->n_entries, db));
+    const int t1 = sw.mark();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    db->t_merge = sw.ms(t0, t1);
+    guard.r = nullptr;
+    *out = db;
+    return IPKGPU_OK;
+}
+
+int ipkgpu_merge_parts_ptrs(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, uint32_t n_owners, uint32_t n_sources,
+                            const uint32_t* const* counts_dev, const void* const* entries_dev, ipkgpu_db** out)
+{
+    if (!ctx) return IPKGPU_ERR_INVALID;
+    if (!out) return fail(ctx, IPKGPU_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!counts_dev || !entries_dev) return fail(ctx, IPKGPU_ERR_INVALID, "null input pointer");
+    if ((sigma != 4 && sigma != 20) || k < 2 || k > ipkgpu_max_k(sigma)) return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
+    if (n_owners == 0 || owner >= n_owners || n_sources == 0) return fail(ctx, IPKGPU_ERR_INVALID, "bad owner/source counts");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t T = ipow(sigma, (int)k);
+    const uint64_t slots = (T + n_owners - 1) / n_owners;
+    ipkgpu_db* db = new (std::nothrow) ipkgpu_db();
+    if (!db) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
+    db->ctx = ctx;
+    struct Guard { ipkgpu_db* r; ~Guard() { if (r) ipkgpu_db_free(r); } } guard{db};
+    Stopwatch sw(ctx->stream);
+    const int t0 = sw.mark();
+    std::vector<const uint32_t*> crow(counts_dev, counts_dev + n_sources);
+    std::vector<const uint2*> srow(n_sources);
+    for (uint32_t s = 0; s < n_sources; ++s) srow[s] = reinterpret_cast<const uint2*>(entries_dev[s]);
+    RC_TRY(ensure(ctx, ctx->counts, slots * 4));
+    RC_TRY(merge_sources(ctx, sigma, k, owner, n_owners, n_sources, slots, crow, srow, ctx->counts.as<uint32_t>(), &db->d_entries, &db->n_entries, db));
     const int t1 = sw.mark();
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     db->t_merge = sw.ms(t0, t1);
@@ -1819,8 +1864,8 @@ int ipkgpu_db_from_parts(ipkgpu_ctx* ctx, ipkgpu_parts* parts, uint32_t sigma, u
     RC_TRY(ensure(ctx, ctx->tmp_b, (slots + 1) * 8));
     RC_TRY(ensure(ctx, ctx->counts, slots * 4));
     RC_TRY(ensure(ctx, ctx->offsets, (slots + 1) * 8));
-    hipLaunchKernelGGL(merge_sum_counts_kernel, dim3((uint32_t)((slots + 255) / 256)), dim3(256), 0, ctx->stream,
-                       parts->d_counts, 1u, slots, ctx->counts.as<uint32_t>(), ctx->tmp_a.as<uint32_t>());
+    hipLaunchKernelGGL(flags_from_counts_kernel, dim3((uint32_t)((slots + 255) / 256)), dim3(256), 0, ctx->stream,
+                       parts->d_counts, slots, ctx->counts.as<uint32_t>(), ctx->tmp_a.as<uint32_t>());
     HIP_TRY(ctx, hipGetLastError());
     RC_TRY(scan_u32(ctx, parts->d_counts, slots, ctx->tmp_b.as<uint64_t>()));
     RC_TRY(scan_u32(ctx, ctx->tmp_a.as<uint32_t>(), slots, ctx->offsets.as<uint64_t>()));
@@ -2086,3 +2131,5 @@ int ipkgpu_db_write(ipkgpu_ctx* ctx, ipkgpu_db* db, const ipkgpu_db_header* h, c
 }
 
 }  // extern "C"
+
+#include "comm_rccl.hpp"

@@ -248,23 +248,24 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
 }
 
 // ---- merge of S sources for one owner -----------------------------------------------------------
-__global__ __launch_bounds__(256) void merge_sum_counts_kernel(const uint32_t* __restrict__ counts, uint32_t S,
+// Every source brings its own counts row [slots] and its own entry block: counts[s], src[s] are device pointers.
+__global__ __launch_bounds__(256) void merge_sum_counts_kernel(const uint32_t* const* __restrict__ counts, uint32_t S,
                                                                uint64_t slots, uint32_t* __restrict__ total,
                                                                uint32_t* __restrict__ flags)
 {
     const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= slots) return;
     uint32_t c = 0;
-    for (uint32_t s = 0; s < S; ++s) c += counts[(size_t)s * slots + q];
+    for (uint32_t s = 0; s < S; ++s) c += counts[s][q];
     total[q] = c;
     flags[q] = (c != 0u);
 }
 
 // One wavefront per slot: copies the slot's entries of every source, in source order.
-// src_off[s][q] = exclusive scan of source s's counts (+ its base in `src`).
-__global__ __launch_bounds__(256) void merge_copy_kernel(const uint32_t* __restrict__ counts, uint32_t S, uint64_t slots,
+// src_off[s][q] = exclusive scan of source s's counts (relative to the source's own block).
+__global__ __launch_bounds__(256) void merge_copy_kernel(const uint32_t* const* __restrict__ counts, uint32_t S, uint64_t slots,
                                                          const uint64_t* __restrict__ src_off,   // [S][slots+1]
-                                                         const uint2* __restrict__ src,
+                                                         const uint2* const* __restrict__ src,
                                                          const uint64_t* __restrict__ dst_off,   // [slots+1]
                                                          uint2* __restrict__ dst)
 {
@@ -273,11 +274,22 @@ __global__ __launch_bounds__(256) void merge_copy_kernel(const uint32_t* __restr
     const uint32_t lane = lane_id();
     uint64_t d = dst_off[q];
     for (uint32_t s = 0; s < S; ++s) {
-        const uint32_t n = counts[(size_t)s * slots + q];
-        const uint64_t so = src_off[(size_t)s * (slots + 1) + q];
-        for (uint32_t i = lane; i < n; i += 64) dst[d + i] = src[so + i];
+        const uint32_t n = counts[s][q];
+        const uint2* from = src[s] + src_off[(size_t)s * (slots + 1) + q];
+        for (uint32_t i = lane; i < n; i += 64) dst[d + i] = from[i];
         d += n;
     }
+}
+
+// single source: total = counts, flags = (counts != 0)
+__global__ __launch_bounds__(256) void flags_from_counts_kernel(const uint32_t* __restrict__ counts, uint64_t slots,
+                                                                uint32_t* __restrict__ total, uint32_t* __restrict__ flags)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= slots) return;
+    const uint32_t c = counts[q];
+    total[q] = c;
+    flags[q] = (c != 0u);
 }
 
 __global__ void add_base_kernel(uint64_t* __restrict__ v, uint64_t n, uint64_t base)

@@ -296,6 +296,25 @@ def _bind_keymajor(L):
     L.ipkgpu_merge_parts.restype = C.c_int
     L.ipkgpu_merge_parts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_void_p, u64p, C.POINTER(C.c_void_p)]
+    L.ipkgpu_merge_parts_ptrs.restype = C.c_int
+    L.ipkgpu_merge_parts_ptrs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.ipkgpu_comm_unique_id.restype = C.c_int
+    L.ipkgpu_comm_unique_id.argtypes = [C.c_void_p]
+    L.ipkgpu_comm_init.restype = C.c_int
+    L.ipkgpu_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    for n in ("ipkgpu_comm_rank", "ipkgpu_comm_world"):
+        getattr(L, n).restype = C.c_int
+        getattr(L, n).argtypes = [C.c_void_p]
+    L.ipkgpu_exchange_begin.restype = C.c_int
+    L.ipkgpu_exchange_begin.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.ipkgpu_exchange_merge.restype = C.c_int
+    L.ipkgpu_exchange_merge.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_double)]
+    L.ipkgpu_xfer_exposed_ms.restype = C.c_double
+    L.ipkgpu_xfer_exposed_ms.argtypes = [C.c_void_p]
+    L.ipkgpu_xfer_free.restype = None
+    L.ipkgpu_xfer_free.argtypes = [C.c_void_p]
     L.ipkgpu_db_from_parts.restype = C.c_int
     L.ipkgpu_db_from_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.ipkgpu_db_num_keys.restype = C.c_uint64
@@ -343,6 +362,8 @@ ABI_SYMBOLS += [
     "ipkgpu_score_threshold", "ipkgpu_db_filter_mif0", "ipkgpu_db_filter_values", "ipkgpu_db_filter_values_f64",
     "ipkgpu_db_filter_order", "ipkgpu_db_filter_values_device", "ipkgpu_db_filter_order_device",
     "ipkgpu_db_filter_time_ms",
+    "ipkgpu_merge_parts_ptrs", "ipkgpu_comm_unique_id", "ipkgpu_comm_init", "ipkgpu_comm_rank", "ipkgpu_comm_world",
+    "ipkgpu_exchange_begin", "ipkgpu_exchange_merge", "ipkgpu_xfer_exposed_ms", "ipkgpu_xfer_free",
 ]
 
 
@@ -497,7 +518,7 @@ def _score_groups_keymajor(self, logp, mat_group, k, log_eps, n_owners=1, sigma=
         if not logp.is_cuda or not logp.is_contiguous() or logp.dtype.itemsize != 4:
             raise ValueError("device path needs a contiguous float32 CUDA tensor")
         n_mats, sites, sigma = logp.shape
-        ptr = logp.data_ptr()
+        ptr = logp.data_ptr() if n_mats else 0
         import torch
         torch.cuda.current_stream().synchronize()
     else:
@@ -527,6 +548,60 @@ def _merge_parts(self, sigma, k, owner, n_owners, counts, entries, source_offset
     return Db(self._lib, out)
 
 
+def _merge_parts_ptrs(self, sigma, k, owner, n_owners, counts_ptrs, entries_ptrs):
+    """One (counts row, entry block) device pointer pair per source, in source order."""
+    _bind_keymajor(self._lib)
+    n = len(counts_ptrs)
+    cp = (C.c_void_p * n)(*[int(x) for x in counts_ptrs])
+    ep = (C.c_void_p * n)(*[int(x) for x in entries_ptrs])
+    out = C.c_void_p()
+    rc = self._lib.ipkgpu_merge_parts_ptrs(self._h, sigma, k, owner, n_owners, n, cp, ep, C.byref(out))
+    if rc != 0:
+        raise self._err(rc)
+    return Db(self._lib, out)
+
+
+def _comm_unique_id(self):
+    _bind_keymajor(self._lib)
+    buf = (C.c_uint8 * 128)()
+    rc = self._lib.ipkgpu_comm_unique_id(buf)
+    if rc != 0:
+        raise IpkGpuError(rc, self._lib.ipkgpu_last_error(None).decode())
+    return bytes(buf)
+
+
+def _comm_init(self, unique_id, rank, world):
+    """RCCL communicator of this context (the id's 128 bytes come from rank 0's comm_unique_id)."""
+    _bind_keymajor(self._lib)
+    buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+    rc = self._lib.ipkgpu_comm_init(self._h, buf, rank, world)
+    if rc != 0:
+        raise self._err(rc)
+    self.comm_world, self.comm_rank = world, rank
+
+
+def _exchange_begin(self, parts):
+    out = C.c_void_p()
+    rc = self._lib.ipkgpu_exchange_begin(self._h, parts._h, C.byref(out))
+    if rc != 0:
+        raise self._err(rc)
+    return out
+
+
+def _exchange_merge(self, xfers, sigma, k):
+    """-> (Db, exposed transfer time in ms); frees the transfer handles."""
+    n = len(xfers)
+    arr = (C.c_void_p * n)(*[x.value for x in xfers])
+    out = C.c_void_p()
+    exposed = C.c_double(0.0)
+    rc = self._lib.ipkgpu_exchange_merge(self._h, arr, n, sigma, k, C.byref(out), C.byref(exposed))
+    for x in xfers:
+        self._lib.ipkgpu_xfer_free(x)
+    if rc != 0:
+        raise self._err(rc)
+    return Db(self._lib, out), float(exposed.value)
+
+
 def _db_from_parts(self, parts, sigma, k):
     """Single-owner parts -> database without copying the entries (they move into the Db)."""
     _bind_keymajor(self._lib)
@@ -539,5 +614,12 @@ def _db_from_parts(self, parts, sigma, k):
 
 
 Engine.db_from_parts = _db_from_parts
+Engine.merge_parts_ptrs = _merge_parts_ptrs
+Engine.comm_unique_id = _comm_unique_id
+Engine.comm_init = _comm_init
+Engine.exchange_begin = _exchange_begin
+Engine.exchange_merge = _exchange_merge
+Engine.comm_world = 1
+Engine.comm_rank = 0
 Engine.score_groups_keymajor = _score_groups_keymajor
 Engine.merge_parts = _merge_parts

@@ -47,7 +47,8 @@ def _worker(rank, world, port, sigma, k, n_groups, out_dir):
             keys, scores, _ = co.explore_group(mats[g * mpg:(g + 1) * mpg], k, eps)
             mine.append((100 + g, keys, scores))
         counts, entries, owner_off = dbo.np_parts(mine, sigma, k, world)
-        rc, re_, so = D.exchange_parts(torch.from_numpy(counts), torch.from_numpy(entries), owner_off, dist, world)
+        rc, re_, rs = D.exchange_parts(torch.from_numpy(counts), torch.from_numpy(entries), owner_off, dist, world)
+        so = np.concatenate([[0], np.cumsum(rs)[:-1]]).astype(np.uint64)
         keys, off, br, sc = dbo.np_merge(rc.numpy(), re_.numpy(), so, sigma, k, rank, world)
         np.savez(os.path.join(out_dir, f"shard{rank}.npz"), keys=dbo.pack_code(keys, sigma, k), off=off, br=br, sc=sc)
     finally:
@@ -70,3 +71,37 @@ def test_exchange_matches_single_process_db(tmp_path, world, sigma, k):
         assert np.array_equal(z["br"], br) and np.array_equal(z["sc"], sc)
         seen += len(keys)
     assert seen == len(full)
+
+
+def test_piece_cuts():
+    g = np.array([5, 5, 9, 9, 2, 2, 7, 7], dtype=np.uint32)
+    assert D.piece_cuts(g, 1) == [0, 8] and D.piece_cuts(g, 2) == [0, 4, 8] and D.piece_cuts(g, 4) == [0, 2, 4, 6, 8]
+    assert D.piece_cuts(g, 3) == [0, 4, 6, 8]                       # 4 groups over 3 pieces: 2 + 1 + 1
+    assert D.piece_cuts(g[:2], 4) == [0, 2, 2, 2, 2]                # fewer groups than pieces: trailing pieces empty
+    assert D.piece_cuts(np.zeros(0, np.uint32), 3) == [0, 0, 0, 0]  # a rank without groups still cuts
+    assert D.piece_cuts(np.array([1, 2, 1, 2]), 2) is None          # interleaved matrices cannot be sliced
+    assert D.piece_cuts(np.array([1, 2, 1, 2]), 1) == [0, 4]
+
+
+def _agree_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0: plenty of groups; rank 1: ONE group; rank 2: no groups at all -- all must end with the same count
+        shapes = [np.repeat(np.arange(6), 2), np.array([40, 40]), np.zeros(0, np.int64)]
+        a = D.agree_on_pieces(shapes[rank], 4, dist, "cpu")
+        # interleaved matrices on one rank only: everybody falls back to one piece
+        shapes2 = [np.repeat(np.arange(6), 2), np.array([1, 2, 1, 2]), np.repeat(np.arange(3), 2)]
+        b = D.agree_on_pieces(shapes2[rank], 4, dist, "cpu")
+        open(os.path.join(out_dir, f"agree{rank}.txt"), "w").write(f"{a} {b}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_piece_count(tmp_path):
+    """Uneven shards, an empty rank and an unsliceable rank must not desynchronise the collectives (one rank issuing
+    fewer exchanges than its peers would hang the job)."""
+    mp.spawn(_agree_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    got = [open(tmp_path / f"agree{r}.txt").read() for r in range(3)]
+    assert got == ["4 1", "4 1", "4 1"]

@@ -288,3 +288,37 @@ def test_mif0_order_matches_the_sequential_oracle(engine):
         ref_order = np.argsort(dbfile.filter_sort_code(ref, np.arange(db.num_keys)), kind="stable")
         assert np.array_equal(order, ref_order.astype(np.uint32))
     db.free(); parts.free()
+
+
+def test_native_exchange_single_rank_comm():
+    """The in-library RCCL exchange (ipkgpu_comm_init / ipkgpu_exchange_begin / ipkgpu_exchange_merge) on a one-rank
+    communicator -- all a one-GPU box can run: sizes and payload travel rank 0 -> rank 0 through grouped ncclSend/ncclRecv,
+    two pieces, merged in (rank, piece) order.  Result = the shard of the single-process database."""
+    import ipk_amd
+    import torch
+    sigma, k = 4, 8
+    mats = synth_matrices(8, 90, sigma, 0.1, 8080)
+    groups = np.array([3, 3, 9, 9, 4, 4, 1, 1], dtype=np.uint32)
+    eps = co.log_threshold(1.5, sigma, k)
+    full, emitted = oracle_db(mats, groups, k, eps)
+    eng = ipk_amd.Engine(0)
+    try:
+        eng.comm_init(eng.comm_unique_id(), 0, 1)
+        dev = torch.from_numpy(mats).cuda()
+        parts = [eng.score_groups_keymajor(dev[a:b], groups[a:b], k, eps, n_owners=1) for a, b in ((0, 4), (4, 8))]
+        xs = [eng.exchange_begin(p) for p in parts]
+        db, exposed = eng.exchange_merge(xs, sigma, k)
+        assert sum(p.emitted for p in parts) == emitted and exposed >= 0.0
+        check_shard(db, full, sigma, k, 0, 1)
+        db.free()
+        # an empty piece (a rank with fewer groups than pieces) takes part with zero counts
+        empty = eng.score_groups_keymajor(dev[0:0], groups[0:0], k, eps, n_owners=1)
+        assert empty.num_entries == 0 and empty.emitted == 0
+        xs = [eng.exchange_begin(parts[0]), eng.exchange_begin(empty), eng.exchange_begin(parts[1])]
+        db, _ = eng.exchange_merge(xs, sigma, k)
+        check_shard(db, full, sigma, k, 0, 1)
+        db.free(); empty.free()
+        for p in parts:
+            p.free()
+    finally:
+        eng.close()
