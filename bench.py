@@ -30,26 +30,33 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cold_end_to_end(eng_warm, cfg, d_logp, groups, eps, device):
-    """Cold build of the benchmarked workload on one GPU, wall clock: what `ipk.py build` pays after its inputs are parsed.
-    The reference prints the same stages (Computation / Filtering / Merge time, db_builder.cpp:217,230-236,288-290,334-336).
-    The warm context is closed first so the new one allocates everything again."""
+def cold_end_to_end(cfg, n_groups, device):
+    """Cold build of the benchmarked workload on one GPU, wall clock, in THIS (fresh) process: what `ipk.py build` pays after
+    its inputs are parsed.  The reference prints the same stages (Computation / Filtering / Merge time,
+    db_builder.cpp:217,230-236,288-290,334-336).  Runs as a child of the benchmark (`--e2e-child`): a context created after
+    another one of the same process has freed tens of GB pays a driver-side penalty of seconds on its first large
+    allocation, which a one-shot build never sees."""
     import shutil
     import tempfile
     import torch
     import ipk_amd
     from ipk_amd import dbfile
-    sigma, k = cfg["sigma"], cfg["k"]
-    host = d_logp.cpu().numpy()                                   # the matrices as the loader leaves them: pageable host memory
-    n_groups = len(np.unique(groups))
-    eng_warm.close()
-    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    from ipk_amd.synth import synth_matrices
+    sigma, k, mpg, sites = cfg["sigma"], cfg["k"], cfg["mats_per_group"], cfg["sites"]
+    eps = ipk_amd.log_threshold(cfg["omega"], sigma, k)
+    n_mats = n_groups * mpg
+    host = np.empty((n_mats, sites, sigma), dtype=np.float32)     # the matrices as the loader leaves them: pageable host memory
+    step_m = max(1, (64 << 20) // (sites * sigma * 4))
+    for m0 in range(0, n_mats, step_m):
+        m1 = min(n_mats, m0 + step_m)
+        host[m0:m1] = synth_matrices(m1 - m0, sites, sigma, cfg["alpha"], cfg["seed"], first_mat=m0)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32), mpg)
     tmpdir = tempfile.mkdtemp(prefix="ipk_e2e_")
     path = os.path.join(tmpdir, "DB.ipk")
     res = {}
     try:
         t_all = time.perf_counter()
-        t0 = time.perf_counter(); eng = ipk_amd.Engine(device); res["create_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); torch.cuda.set_device(device); eng = ipk_amd.Engine(device); res["create_s"] = time.perf_counter() - t0
         t0 = time.perf_counter(); dev = torch.empty(host.shape, dtype=torch.float32, device="cuda"); torch.cuda.synchronize(); res["alloc_s"] = time.perf_counter() - t0
         t0 = time.perf_counter(); dev.copy_(torch.from_numpy(host)); torch.cuda.synchronize(); res["upload_s"] = time.perf_counter() - t0
         t0 = time.perf_counter(); parts = eng.score_groups_keymajor(dev, groups, k, eps, n_owners=1); res["score_first_call_s"] = time.perf_counter() - t0
@@ -65,6 +72,7 @@ def cold_end_to_end(eng_warm, cfg, d_logp, groups, eps, device):
         res["file_bytes"] = nbytes
         res["file_on"] = tmpdir
         res["kmers"], res["entries"], res["scored"] = db.num_keys, db.num_entries, parts.emitted
+        res["score_device_ms"] = parts.time_ms(0)
         db.free(); parts.free(); eng.close()
     finally:
         shutil.rmtree(tmpdir, ignore_errors=True)
@@ -83,7 +91,8 @@ def main():
     ap.add_argument("--cpu-groups", type=int, default=-1, help="groups timed on the CPU oracle (-1 = auto, 0 = skip)")
     ap.add_argument("--variant", type=int, default=0, help="engine option 'variant' (0 = auto; diagnostics: 1 atomics, 2 chunked pool, 3 exact partition)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="strong: the config's groups split over the ranks; weak: a full copy per rank")
-    ap.add_argument("--e2e", type=int, default=1, help="1: also time the cold end-to-end build (N = 1 only); 0: skip")
+    ap.add_argument("--e2e", type=int, default=1, help="1: also time the cold end-to-end build (N = 1 only; in a fresh child process); 0: skip")
+    ap.add_argument("--e2e-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
@@ -91,6 +100,13 @@ def main():
     import ipk_amd
     from ipk_amd import engine as E
     from ipk_amd.synth import CONFIGS, synth_matrices
+
+    if args.e2e_child:
+        cfg = dict(CONFIGS[args.config])
+        if args.alpha:
+            cfg["alpha"] = args.alpha
+        print("E2E " + json.dumps(cold_end_to_end(cfg, args.groups or cfg["n_groups"], int(os.environ.get("IPK_BENCH_DEVICE", "0")))))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -252,8 +268,18 @@ def main():
             "setup_s": {"synth_and_upload": t_gen, "engine_init_first_call": t_init},
         }
         if world == 1 and args.e2e:
+            import subprocess
             try:
-                out["e2e"] = cold_end_to_end(eng, cfg, d_logp, groups, eps, local_rank)
+                eng.close()                                       # the child gets the GPU's memory to itself
+                del d_logp
+                torch.cuda.empty_cache()
+                cmd = [sys.executable, os.path.abspath(__file__), "--e2e-child", "--config", args.config, "--groups", str(ng)]
+                if args.alpha:
+                    cmd += ["--alpha", str(args.alpha)]
+                env = dict(os.environ, IPK_BENCH_DEVICE=str(local_rank))
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+                line = [l for l in pr.stdout.splitlines() if l.startswith("E2E ")]
+                out["e2e"] = json.loads(line[0][4:]) if line else {"error": (pr.stderr or pr.stdout)[-800:]}
             except Exception as exc:                              # e.g. no room for the file: the steady-state line stays valid
                 out["e2e"] = {"error": repr(exc)}
         # CPU baseline: the oracle (C restatement), 1 thread, bounded sample of the same workload
