@@ -168,7 +168,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    acc = {"score": 0.0, "launches": 0.0, "total": 0.0, "compact": 0.0, "prefix": 0.0, "merge": 0.0, "main": 0.0, "reduce": 0.0, "exchange_exposed": 0.0}
+    acc = {"score": 0.0, "launches": 0.0, "total": 0.0, "compact": 0.0, "prefix": 0.0, "merge": 0.0, "main": 0.0, "reduce": 0.0, "exchange_exposed": 0.0,
+           "xp_count": 0.0, "xp_write": 0.0, "km_write": 0.0}
     emitted = entries = n_keys = 0
 
     def step(record):
@@ -188,6 +189,8 @@ def main():
             acc["score"] += t.time_ms(E.T_SCORE); acc["launches"] += t.time_ms(E.T_SCORE_LAUNCHES)
             acc["total"] += t.time_ms(E.T_TOTAL); acc["compact"] += t.time_ms(E.T_COMPACT); acc["prefix"] += t.time_ms(E.T_PREFIX)
             acc["main"] += t.time_ms(E.T_SCORE_MAIN); acc["reduce"] += t.time_ms(E.T_SCORE_REDUCE)
+            if args.output != "group":
+                acc["xp_count"] += t.time_ms(E.T_XP_COUNT); acc["xp_write"] += t.time_ms(E.T_XP_WRITE); acc["km_write"] += t.time_ms(E.T_KM_WRITE)
         t.free()
 
     # engine initialisation (untimed, like data generation): the first call of a context allocates and calibrates its
@@ -202,6 +205,7 @@ def main():
     for _ in range(args.steps):
         step(True)
     barrier()
+    last_kernel = eng.last_main_kernel()
     score_ms, launches, total_ms, compact_ms, prefix_ms = acc["score"], acc["launches"], acc["total"], acc["compact"], acc["prefix"]
     elapsed = time.perf_counter() - t_start
     rank_ms = [elapsed / args.steps * 1e3]
@@ -224,26 +228,48 @@ def main():
         value = emitted_all * args.steps / elapsed
         # roofline of the dominant kernel (scoring + max-reduce): algorithmic bytes per launch =
         # every matrix read once + one (u32 key, f32 score) pair per scored phylo-k-mer
-        b_alg = n_mats * sites * sigma * 4 + 8 * emitted
-        main_kernel = "score_stream_kernel" if acc["reduce"] > 0 else "score_tiles_kernel"
-        if sigma == 20 and k == 6 and acc["reduce"] > 0:
-            main_kernel = "score_xp_kernel (count + write launches together)"     # exact-partition variant scores twice
+        mats_bytes = n_mats * sites * sigma * 4
+        b_alg = mats_bytes + 8 * emitted
+        main_kernel = last_kernel or ("score_stream_kernel" if acc["reduce"] > 0 else "score_tiles_kernel")
         avg_score_ms = score_ms / max(launches, 1)
         avg_main_ms = acc["main"] / max(launches, 1)          # the dominant kernel alone (HIP events on its stream)
         # a step is one launch per batch or, with several ranks, per piece of the rank's groups: bytes per LAUNCH
         b_alg = b_alg * args.steps / max(launches, 1)
         achieved = b_alg / (avg_main_ms * 1e-3) / 1e9 if avg_main_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_kernels = None, {}
         # written by tools/pmc_traffic.py from rocprofv3 --pmc passes (cfg2: pmc_traffic.json, others: pmc_traffic_<config>.json)
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == "cfg2" else f"pmc_traffic_{args.config}.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if (tj.get("workload") == args.config and not args.groups and not args.alpha and not args.variant
-                        and tj.get("kernel", "").startswith(main_kernel.split("_kernel")[0])):
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("workload") == args.config and not args.groups and not args.alpha and not args.variant and world == 1:
+                    traffic_kernels = {kname: kv.get("hbm_bytes_per_launch") for kname, kv in tj.get("kernels", {}).items()}
+                    traffic = traffic_kernels.get(main_kernel)
             except Exception:
                 traffic = None
+        # per-kernel lines: every kernel with its own algorithmic bytes (no lumping); ms = average launch duration from the
+        # library's HIP events.  pairs = scored phylo-k-mers (8 B each), entries = (branch, k-mer) entries (8 B each).
+        per_launch = lambda key: acc[key] / max(launches, 1)
+        e_bytes, p_bytes = 8.0 * entries * args.steps / max(launches, 1), 8.0 * emitted * args.steps / max(launches, 1)
+        kernels = []
+        def kline(name, ms, bytes_):
+            if ms > 0:
+                g = bytes_ / (ms * 1e-3) / 1e9
+                kernels.append({"kernel": name, "avg_launch_ms": ms, "algorithmic_bytes_per_launch": bytes_, "achieved": g, "unit": "GB/s",
+                                "frac": g / HBM_PEAK_GBPS, "traffic": traffic_kernels.get(name)})
+        mb = mats_bytes * args.steps / max(launches, 1)
+        if main_kernel == "score_xp_kernel":
+            main_kernel = "score_xp_kernel<WRITE>"                          # the dominant launch of the exact-partition variant
+            avg_main_ms = per_launch("xp_write")
+            achieved = b_alg / (avg_main_ms * 1e-3) / 1e9 if avg_main_ms > 0 else 0.0
+            kline("score_xp_kernel<COUNT>", per_launch("xp_count"), mb)                 # reads the matrices, writes counters only
+            kline("score_xp_kernel<WRITE>", per_launch("xp_write"), mb + p_bytes)       # the pairs leave here
+            kline("reduce_ranges_kernel", per_launch("reduce"), p_bytes + e_bytes / 2)  # pairs in, one 4-B score code per entry out
+            kline("km_write_c_kernel", per_launch("km_write"), e_bytes / 2 + e_bytes)   # score codes in, 8-B entries out
+        else:
+            kline(main_kernel, avg_main_ms, b_alg)
+            kline("reduce_buckets_kernel", per_launch("reduce"), p_bytes + 4.0 * (sigma ** k) * ng)   # pairs in, dense tables out
+            kline("km_write_kernel", per_launch("km_write"), 4.0 * (sigma ** k) * ng + e_bytes)       # dense tables in, entries out
         out = {
             "metric": "scored phylo-k-mers/sec", "value": value, "unit": "phylo-k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -256,7 +282,7 @@ def main():
                        "sharding": f"branch groups over {world} rank(s)" + ("; k-mer-keyed all-to-all (RCCL) + merge" if world > 1 and args.output == "db" else "; no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": main_kernel, "avg_launch_ms": avg_main_ms,
+                         "kernel": main_kernel, "avg_launch_ms": avg_main_ms, "kernels": kernels,
                          "algorithmic_bytes_per_launch": b_alg,
                          "score_phase_ms": avg_score_ms, "score_phase_GBps": b_alg / (avg_score_ms * 1e-3) / 1e9 if avg_score_ms > 0 else 0.0},
             "phases_ms_per_step": {"prefix": prefix_ms / args.steps, "score": score_ms / args.steps,

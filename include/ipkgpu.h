@@ -54,7 +54,10 @@ enum {
     IPKGPU_T_SCORE_LAUNCHES = 4,/* number of scoring passes (batches of groups) the sums cover */
     IPKGPU_T_SCORE_MAIN = 5,    /* the dominant kernel alone: list building + pair emission (score_stream_kernel /
                                    score_tiles_kernel), summed over batches */
-    IPKGPU_T_SCORE_REDUCE = 6   /* per-bucket LDS max-reduce (reduce_buckets_kernel / reduce_ranges_kernel) */
+    IPKGPU_T_SCORE_REDUCE = 6,  /* per-bucket LDS max-reduce (reduce_buckets_kernel / reduce_ranges_kernel) */
+    IPKGPU_T_XP_COUNT = 7,      /* exact-partition variant: the count pass alone (parts only) */
+    IPKGPU_T_XP_WRITE = 8,      /* exact-partition variant: the write pass alone (parts only) */
+    IPKGPU_T_KM_WRITE = 9       /* key-major writer kernel alone (km_write_kernel / km_write_c_kernel; parts only) */
 };
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -67,6 +70,9 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx);
 /* Message of the last failing call on this context ("" if none); owned by the context.
  * ipkgpu_last_error(NULL) returns the message of the last failed ipkgpu_create. */
 const char* ipkgpu_last_error(const ipkgpu_ctx* ctx);
+/* Name of the dominant kernel of the context's last scoring call ("score_quad_kernel", "score_stream_kernel",
+ * "score_xp_kernel", "score_tiles_kernel"): what IPKGPU_T_SCORE_MAIN timed. */
+const char* ipkgpu_last_main_kernel(const ipkgpu_ctx* ctx);
 
 /* Options: "workspace_bytes" (max bytes of per-group score tables resident at once; groups are
  * processed in batches that fit); "variant" (0 = auto: LDS max-reduce fed by the chunked pair pool, or by

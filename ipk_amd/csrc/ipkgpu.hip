@@ -79,6 +79,8 @@ struct ipkgpu_ctx {
     uint32_t comp_nb = 0, comp_stride = 0, comp_tbl = 0;
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
     double acc_main_ms = 0, acc_reduce_ms = 0;   // dominant scoring kernel / LDS reduce pass of the current call
+    double acc_count_ms = 0, acc_write_ms = 0, acc_km_ms = 0;   // exact-partition count / write pass, key-major writer
+    const char* main_kernel = "";                // name of the dominant kernel of the last scoring call
     // caching allocator for result buffers: hipMalloc/hipFree of multi-GB blocks costs 10-100 ms, so
     // released result buffers are kept (bounded) and handed out again to the next call
     std::vector<std::pair<void*, size_t>> free_blocks;
@@ -114,7 +116,7 @@ struct ipkgpu_parts {
     uint2* d_entries = nullptr;               // owner-major, key-major, group order: (branch, score bits)
     std::vector<uint64_t> owner_off;          // [n_owners + 1] entry offsets
     uint64_t emitted = 0;
-    double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0, t_main = 0, t_reduce = 0;
+    double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0, t_main = 0, t_reduce = 0, t_count = 0, t_write = 0, t_km = 0;
     int score_launches = 0;
 };
 
@@ -487,7 +489,7 @@ template <int SIGMA, int K> size_t quad_lds()
                (size_t)quad_nw<SIGMA, K>() * NB * 8;
     }
 }
-template <int SIGMA, int K>
+template <int SIGMA, int K, bool COUNT_ONLY = false>
 int launch_quad_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
 {
     if constexpr (!quad_ok<SIGMA, K>()) { (void)sp; (void)n_wg; return fail(ctx, IPKGPU_ERR_INVALID, "quad kernel unsupported for this sigma/k"); }
@@ -496,7 +498,7 @@ int launch_quad_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
         constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
         constexpr int QNW = quad_nw<SIGMA, K>(), QTW = quad_tw<SIGMA, K>();
         const size_t lds = quad_lds<SIGMA, K>();
-        auto kern = score_quad_kernel<SIGMA, K, CAP, QTW, QNW, TBL>;
+        auto kern = score_quad_kernel<SIGMA, K, CAP, QTW, QNW, TBL, COUNT_ONLY>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(QNW * 64), lds, ctx->stream, sp);
@@ -671,9 +673,9 @@ size_t quad_lds_bytes(uint32_t sigma, uint32_t k)
 #undef M_QLDS
     return 0;
 }
-int dispatch_quad_pass1(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const StreamParams& sp, uint32_t n_wg)
+int dispatch_quad_pass1(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const StreamParams& sp, uint32_t n_wg, bool count_only = false)
 {
-#define M_Q1(S_, K_) return launch_quad_pass1<S_, K_>(ctx, sp, n_wg)
+#define M_Q1(S_, K_) return count_only ? launch_quad_pass1<S_, K_, true>(ctx, sp, n_wg) : launch_quad_pass1<S_, K_, false>(ctx, sp, n_wg)
     IPK_DISPATCH(sigma, k, M_Q1);
 #undef M_Q1
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
@@ -919,7 +921,9 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     ctx->table_compressed = compress;
     ctx->comp_nb = XNB; ctx->comp_stride = stride; ctx->comp_tbl = xp_bucket_slots(pl.sigma, pl.k);
     ctx->acc_main_ms += sw.ms(ev_a, ev_a2) + sw.ms(ev_c, ev_d0);
+    ctx->acc_count_ms += sw.ms(ev_a, ev_a2); ctx->acc_write_ms += sw.ms(ev_c, ev_d0);
     ctx->acc_reduce_ms += sw.ms(ev_d, ev_e);
+    ctx->main_kernel = "score_xp_kernel";
     return IPKGPU_OK;
 }
 
@@ -986,6 +990,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         const int b = sw.mark();
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->acc_main_ms += sw.ms(a, b);
+        ctx->main_kernel = "score_tiles_kernel";
         return IPKGPU_OK;
     }
 
@@ -1039,7 +1044,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         ss.pool = nullptr; ss.pool_cap = 0; ss.pool_next = nullptr; ss.desc = nullptr; ss.pool_ovf = nullptr;
         ss.emitted = p.emitted; ss.ovf_queue = p.ovf_queue; ss.ovf_count = p.ovf_count; ss.mat_slot = p.mat_slot;
         ss.flags = 2u;
-        if (use_quad) RC_TRY(dispatch_quad_pass1(ctx, pl.sigma, pl.k, ss, n_s * ss.S));
+        if (use_quad) RC_TRY(dispatch_quad_pass1(ctx, pl.sigma, pl.k, ss, n_s * ss.S, true));
         else RC_TRY(dispatch_stream_pass1(ctx, pl.sigma, pl.k, ss, n_s * ss.S));
         unsigned long long se = 0; uint32_t so = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&se, p.emitted, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1179,6 +1184,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         ctx->mask_valid = true;
         ctx->acc_main_ms += sw.ms(ev_a, ev_b);
         ctx->acc_reduce_ms += sw.ms(ev_c, ev_d);
+        ctx->main_kernel = use_quad ? "score_quad_kernel" : "score_stream_kernel";
         return IPKGPU_OK;
     }
     return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool could not be sized");
@@ -1245,7 +1251,7 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
     RC_TRY(ensure(ctx, ctx->offsets, (size_t)(pl.gpb * cpg + 1) * 8));
     RC_TRY(ensure(ctx, ctx->goff, (size_t)(pl.gpb + 1) * 8));
 
-    ctx->acc_main_ms = ctx->acc_reduce_ms = 0;
+    ctx->acc_main_ms = ctx->acc_reduce_ms = ctx->acc_count_ms = ctx->acc_write_ms = ctx->acc_km_ms = 0;
     Stopwatch sw(ctx->stream);
     const int t_begin = sw.mark();
     RC_TRY(run_prefix(ctx, pl, logp_dev));
@@ -1388,7 +1394,7 @@ int ipkgpu_score_groups_positions(ipkgpu_ctx* ctx, const float* logp, uint32_t n
     RC_TRY(ensure(ctx, ctx->counts, (size_t)(pl.gpb * cpg) * 4));
     RC_TRY(ensure(ctx, ctx->offsets, (size_t)(pl.gpb * cpg + 1) * 8));
     RC_TRY(ensure(ctx, ctx->goff, (size_t)(pl.gpb + 1) * 8));
-    ctx->acc_main_ms = ctx->acc_reduce_ms = 0;
+    ctx->acc_main_ms = ctx->acc_reduce_ms = ctx->acc_count_ms = ctx->acc_write_ms = ctx->acc_km_ms = 0;
     Stopwatch sw(ctx->stream);
     const int t_begin = sw.mark();
     RC_TRY(run_prefix(ctx, pl, d_logp));
@@ -1648,12 +1654,12 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     HIP_TRY(ctx, hipMemcpyAsync(ctx->branch.p, pl.group_ids.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
-    ctx->acc_main_ms = ctx->acc_reduce_ms = 0;
+    ctx->acc_main_ms = ctx->acc_reduce_ms = ctx->acc_count_ms = ctx->acc_write_ms = ctx->acc_km_ms = 0;
     Stopwatch sw(ctx->stream);
     const int t_begin = sw.mark();
     RC_TRY(run_prefix(ctx, pl, logp_dev));
     const int t_pre = sw.mark();
-    std::vector<std::pair<int, int>> ev_score, ev_compact;
+    std::vector<std::pair<int, int>> ev_score, ev_compact, ev_km;
     std::vector<uint32_t> idx_host;
 
     struct Batch { uint32_t* counts = nullptr; uint2* entries = nullptr; std::vector<uint64_t> owner_off; };
@@ -1695,6 +1701,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         HIP_TRY(ctx, hipMemcpyAsync(b.owner_off.data(), ctx->goff.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.entries, std::max<uint64_t>(b.owner_off[P], 1) * 8));
+        const int km0 = sw.mark();
         if (ctx->table_compressed) {
             const uint64_t per_xcd = (((T + 63) / 64) + 7) / 8;
             hipLaunchKernelGGL(km_write_c_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
@@ -1705,7 +1712,9 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
                                ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
                                ctx->offsets.as<uint64_t>(), b.entries);
         HIP_TRY(ctx, hipGetLastError());
-        ev_compact.push_back({s1, sw.mark()});
+        const int km1 = sw.mark();
+        ev_km.push_back({km0, km1});
+        ev_compact.push_back({s1, km1});
     }
 
     if (batches.size() == 1) {
@@ -1743,7 +1752,9 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     parts->t_total = sw.ms(t_begin, t_end);
     parts->t_prefix = sw.ms(t_begin, t_pre);
     for (auto& pr : ev_score) parts->t_score += sw.ms(pr.first, pr.second);
+    for (auto& pr : ev_km) ctx->acc_km_ms += sw.ms(pr.first, pr.second);
     parts->t_main = ctx->acc_main_ms; parts->t_reduce = ctx->acc_reduce_ms;
+    parts->t_count = ctx->acc_count_ms; parts->t_write = ctx->acc_write_ms; parts->t_km = ctx->acc_km_ms;
     for (auto& pr : ev_compact) parts->t_compact += sw.ms(pr.first, pr.second);
     guard.r = nullptr;
     *out = parts;
@@ -1767,6 +1778,9 @@ double ipkgpu_parts_time_ms(const ipkgpu_parts* p, int which)
         case IPKGPU_T_SCORE_LAUNCHES: return (double)p->score_launches;
         case IPKGPU_T_SCORE_MAIN: return p->t_main;
         case IPKGPU_T_SCORE_REDUCE: return p->t_reduce;
+        case IPKGPU_T_XP_COUNT: return p->t_count;
+        case IPKGPU_T_XP_WRITE: return p->t_write;
+        case IPKGPU_T_KM_WRITE: return p->t_km;
     }
     return 0;
 }
@@ -2007,6 +2021,7 @@ struct FileOut {
 extern "C" {
 
 const char* ipkgpu_db_write_last_error(void) { return g_write_err.c_str(); }
+const char* ipkgpu_last_main_kernel(const ipkgpu_ctx* ctx) { return ctx ? ctx->main_kernel : ""; }
 double ipkgpu_db_write_time_s(const ipkgpu_ctx* ctx, int which)
 {
     if (!ctx) return 0;

@@ -215,7 +215,9 @@ struct RowAppender {
     }
 };
 
-template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL>
+// COUNT_ONLY: the pool-sizing pre-pass of a context's first call -- same windows, same lists, the final join only counts its
+// survivors (nothing is reserved or stored); a separate instantiation so that it shows under its own name in a kernel trace.
+template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL, bool COUNT_ONLY = false>
 __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
     const float lane_h = (float)lane + 0.5f;
     const float eps = p.eps;
     const bool st_ok = !(p.flags & 1u);
-    const bool count_only = (p.flags & 2u) != 0;     // count the scored pairs only: nothing is reserved or stored
+    constexpr bool count_only = COUNT_ONLY;
     // per step: the node this lane's slot evaluates
     uint32_t st_j4[Q::NSTEPS], st_th[Q::NSTEPS], st_off[Q::NSTEPS], st_cmul[Q::NSTEPS], st_code[Q::NSTEPS];
     bool st_on[Q::NSTEPS];
@@ -407,11 +409,11 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                             any |= m[u];
                         }
                         if (any == 0) return;
-                        if (count_only) {                                             // flag 2: the pool-sizing pre-pass
+                        if constexpr (count_only) {                                   // the pool-sizing pre-pass
 #pragma unroll
                             for (int u = 0; u < NS; ++u) emitted += (uint32_t)__popcll(m[u]);
                             return;
-                        }
+                        } else {
                         uint32_t rank[NS], bk[NS]; unsigned long long got[NS];
 #pragma unroll
                         for (int u = 0; u < NS; ++u) {
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                                 ovf[u] &= ~ballot64(h);
                                 anyo |= ovf[u];
                             }
+                        }
                         }
                     };
                     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;

@@ -155,7 +155,7 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
     first.exchange_exposed_ms = exposed
     for pj in scored[1:]:
         first.emitted += pj.emitted
-        for which in range(7):                                           # IPKGPU_T_* selectors
+        for which in range(10):                                          # IPKGPU_T_* selectors
             first.extra_ms[which] = first.extra_ms.get(which, 0.0) + pj.time_ms(which)
         pj.free()
     return db, first

@@ -14,11 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libipkgpu.so")
 _lib = None
 
-T_TOTAL, T_PREFIX, T_SCORE, T_COMPACT, T_SCORE_LAUNCHES, T_SCORE_MAIN, T_SCORE_REDUCE = range(7)
+T_TOTAL, T_PREFIX, T_SCORE, T_COMPACT, T_SCORE_LAUNCHES, T_SCORE_MAIN, T_SCORE_REDUCE, T_XP_COUNT, T_XP_WRITE, T_KM_WRITE = range(10)
 
 # every symbol include/ipkgpu.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "ipkgpu_create", "ipkgpu_destroy", "ipkgpu_last_error", "ipkgpu_set_option",
+    "ipkgpu_create", "ipkgpu_destroy", "ipkgpu_last_error", "ipkgpu_last_main_kernel", "ipkgpu_set_option",
     "ipkgpu_log_threshold", "ipkgpu_bits_per_symbol", "ipkgpu_kmer_batch", "ipkgpu_max_k",
     "ipkgpu_score_groups", "ipkgpu_score_groups_device",
     "ipkgpu_result_num_groups", "ipkgpu_result_group_ids", "ipkgpu_result_offsets",
@@ -57,6 +57,8 @@ def load_library():
     L.ipkgpu_destroy.argtypes = [C.c_void_p]
     L.ipkgpu_last_error.restype = C.c_char_p
     L.ipkgpu_last_error.argtypes = [C.c_void_p]
+    L.ipkgpu_last_main_kernel.restype = C.c_char_p
+    L.ipkgpu_last_main_kernel.argtypes = [C.c_void_p]
     L.ipkgpu_set_option.restype = C.c_int
     L.ipkgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.ipkgpu_log_threshold.restype = C.c_float
@@ -203,6 +205,9 @@ class Engine:
 
     def _err(self, rc):
         return IpkGpuError(rc, self._lib.ipkgpu_last_error(self._h).decode())
+
+    def last_main_kernel(self):
+        return self._lib.ipkgpu_last_main_kernel(self._h).decode()
 
     def set_option(self, name, value):
         rc = self._lib.ipkgpu_set_option(self._h, name.encode(), int(value))
