@@ -154,64 +154,115 @@ __device__ __forceinline__ uint32_t to_sgpr(uint32_t x)
     return r;
 }
 
-// A pool store.  (A structured-buffer form -- buffer_store ... idxen offen with one record per chunk, which would leave the
-// 64-bit address arithmetic to the hardware -- was tried and is WRONG here: the buffer unit forms index * stride + offset in
-// 32 bits, so chunks past 4 GiB wrap around.  The pool is tens of GB.)
-__device__ __forceinline__ void pool_store(uint2* pool, uint32_t chunk, uint32_t slot, uint2 val)
+// A pool store: wave-uniform base (SGPR pair) + 32-bit byte offset, i.e. the `global_store v_off, v_data, s[base]` form -- one
+// VALU instruction of address arithmetic per store instead of four for a 64-bit lane address.  The offsets are relative to the
+// wave's base chunk (RowAppender::rebase keeps every open chunk within 4 GiB of it).  (A structured-buffer form -- buffer_store
+// ... idxen offen with one record per chunk -- was tried and is WRONG here: the buffer unit forms index * stride + offset in 32
+// bits relative to the POOL's base, so chunks past 4 GiB wrap around.  The pool is tens of GB.)
+__device__ __forceinline__ void pool_store(uint2* wave_base, uint32_t byte_off, uint2 val)
 {
-    pool[(size_t)chunk * CH + slot] = val;
+    const unsigned long long data = ((unsigned long long)val.y << 32) | val.x;
+    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(byte_off), "v"(data), "s"(wave_base) : "memory");
 }
+// (x << 3) + y as ONE instruction (left to itself the compiler shares x << 3 with the rarely taken chunk-roll path and adds separately)
+__device__ __forceinline__ uint32_t lshl3_add(uint32_t x, uint32_t y)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// The same store for the lanes of `mask`, from code that runs with ALL lanes enabled (uniform control flow in full wavefronts):
+// two scalar instructions around the store instead of the compiler's and-saveexec / branch-if-empty / restore sequence --
+// the kernel is as short of scalar issue slots as of vector ones.
+__device__ __forceinline__ void pool_store_lanes(uint2* wave_base, uint32_t byte_off, uint2 val, uint64_t mask)
+{
+    const unsigned long long data = ((unsigned long long)val.y << 32) | val.x;
+    asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_mov_b64 exec, -1"
+                 : : "v"(byte_off), "v"(data), "s"(wave_base), "s"(mask) : "memory");
+}
+
+constexpr uint32_t QUAD_SPAN_CHUNKS = 1u << 21;   // chunks of CH * 8 = 2 KiB: 2^21 of them span 4 GiB
+constexpr uint32_t QUAD_SPAN_TEST = 8;            // debug_flags bit 3: rebase every 8 chunks (tests of the rebasing path)
 
 // floor(x / n) for 0 <= x < 128, 1 <= n <= 64, with rn = 1 / n to within a few ulp: (x + 0.5) / n is at least 1 / 128 away from every
 // integer, far more than the rounding error of the product
 __device__ __forceinline__ uint32_t div_small(float x_plus_half, float rn) { return (uint32_t)(x_plus_half * rn); }
 
-// Per-wave pair appender with one {fill, chunk} 64-bit word per key bucket (low word: pairs reserved in the open
-// chunk, high word: the chunk's id).  "No chunk" is the id pool_cap: the pool holds one spare chunk there, so a
-// store that goes through a missing chunk (initial state, exhausted pool) needs no test and harms nothing.  The
-// initial state {CH, spare} makes the first reservation roll.
+// Per-wave pair appender with one {fill, where} 64-bit word per key bucket: low word = pairs reserved in the bucket's open
+// chunk, high word = the chunk's byte offset from the wave's base chunk (NONE: no open chunk).  The initial state {CH, NONE}
+// makes the first reservation roll; a fill >= CH never stores, so NONE is never used as an offset.
+//
+// base_id: chunk ids are drawn from one global counter, so a wave's open chunks are spread over everything allocated during
+// its life.  When a new chunk lies 4 GiB or more past the base (or the pool is exhausted: then the "chunk" is the spare one at
+// id pool_cap, which absorbs the stores of a launch that is going to be repeated with a bigger pool), every open chunk is
+// closed as it is -- a descriptor may hold any count <= CH -- and the new chunk becomes the base.
 template <uint32_t NB>
 struct RowAppender {
+    static constexpr uint32_t NONE = 0xFFFFFFFFu;
+    static constexpr uint32_t CHUNK_BYTES = CH * 8u;
     const StreamParams& p;
     unsigned long long* st;                 // [NB]
     uint32_t g;
     uint32_t chunk_next = 0, chunk_end = 0;
+    uint32_t base_id = 0;
+    uint2* base = nullptr;                  // p.pool + base_id * CH
 
     __device__ __forceinline__ void init()
     {
-        for (uint32_t b = lane_id(); b < NB; b += 64) st[b] = ((unsigned long long)p.pool_cap << 32) | (unsigned long long)CH;
+        for (uint32_t b = lane_id(); b < NB; b += 64) st[b] = ((unsigned long long)NONE << 32) | (unsigned long long)CH;
+        base = p.pool;
     }
-    // bucket b's chunk is full: close it, open a new one; returns the new chunk id (pool_cap = the spare chunk if the pool ran out)
-    __device__ __forceinline__ uint32_t roll(uint32_t b)
+    __device__ __forceinline__ void write_desc(uint32_t b, unsigned long long s)
     {
-        const uint32_t lane = lane_id();
-        if (chunk_next == chunk_end) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(p.pool_next, ALLOC_BATCH);
-            chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            chunk_end = chunk_next + ALLOC_BATCH;
-        }
-        uint32_t nid = chunk_next++;
-        if (nid >= p.pool_cap) { if (lane == 0) atomicOr(p.pool_ovf, 1u); nid = p.pool_cap; }
-        wave_lds_sync();
-        const unsigned long long old = st[b];
-        wave_lds_sync();
-        if (lane == 0) {
-            const uint32_t old_id = (uint32_t)(old >> 32);
-            if (old_id < p.pool_cap) p.desc[old_id] = ((unsigned long long)(g * NB + b) << 32) | (unsigned long long)CH;
-            st[b] = ((unsigned long long)nid << 32) | (unsigned long long)((uint32_t)old - CH);
-        }
-        wave_lds_sync();
-        return nid;
+        const uint32_t where = (uint32_t)(s >> 32);
+        if (where == NONE) return;
+        const uint32_t id = base_id + where / CHUNK_BYTES;
+        if (id < p.pool_cap) p.desc[id] = ((unsigned long long)(g * NB + b) << 32) | (unsigned long long)min((uint32_t)s, CH);
     }
-    __device__ __forceinline__ void close()
+    __device__ __forceinline__ void rebase(uint32_t nid)
     {
         wave_lds_sync();
         for (uint32_t b = lane_id(); b < NB; b += 64) {
             const unsigned long long s = st[b];
-            const uint32_t id = (uint32_t)(s >> 32);
-            if (id < p.pool_cap) p.desc[id] = ((unsigned long long)(g * NB + b) << 32) | (unsigned long long)min((uint32_t)s, CH);
+            write_desc(b, s);
+            st[b] = ((unsigned long long)NONE << 32) | (unsigned long long)max((uint32_t)s, CH);   // (a fill past CH: pairs waiting for the bucket's roll)
         }
+        wave_lds_sync();
+        base_id = nid;
+        const unsigned long long a = (unsigned long long)(p.pool + (size_t)nid * CH);
+        base = reinterpret_cast<uint2*>(((unsigned long long)to_sgpr((uint32_t)(a >> 32)) << 32) | to_sgpr((uint32_t)a));
+    }
+    // bucket b's chunk is full: close it, open a new one; returns the new chunk's byte offset from `base`
+    __device__ __forceinline__ uint32_t roll(uint32_t b)
+    {
+        const uint32_t lane = lane_id();
+        if (chunk_next == chunk_end) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(p.pool_next, ALLOC_BATCH);
+            chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            chunk_end = chunk_next + ALLOC_BATCH;
+        }
+        uint32_t nid = to_sgpr(chunk_next);                             // (opaque: otherwise the ids live in VGPRs, and so would `base`)
+        chunk_next = nid + 1;
+        if (nid >= p.pool_cap && lane == 0) atomicOr(p.pool_ovf, 1u);
+        nid = min(nid, p.pool_cap);                                     // (not assigned under the branch: a value merged after a divergent
+                                                                        //  branch counts as divergent, and the whole state would move to VGPRs)
+        if (nid - base_id >= ((p.flags & 8u) ? QUAD_SPAN_TEST : QUAD_SPAN_CHUNKS)) rebase(nid);
+        const uint32_t where = (nid - base_id) * CHUNK_BYTES;
+        wave_lds_sync();
+        const unsigned long long old = st[b];
+        wave_lds_sync();
+        if (lane == 0) {
+            write_desc(b, old);                                            // (full: its fill is >= CH)
+            st[b] = ((unsigned long long)where << 32) | (unsigned long long)((uint32_t)old - CH);
+        }
+        wave_lds_sync();
+        return where;
+    }
+    __device__ __forceinline__ void close()
+    {
+        wave_lds_sync();
+        for (uint32_t b = lane_id(); b < NB; b += 64) write_desc(b, st[b]);
     }
 };
 
@@ -256,7 +307,6 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
     const uint32_t lt16 = (1u << l16) - 1u;
     const float lane_h = (float)lane + 0.5f;
     const float eps = p.eps;
-    const bool st_ok = !(p.flags & 1u);
     constexpr bool count_only = COUNT_ONLY;
     // per step: the node this lane's slot evaluates
     uint32_t st_j4[Q::NSTEPS], st_th[Q::NSTEPS], st_off[Q::NSTEPS], st_cmul[Q::NSTEPS], st_code[Q::NSTEPS];
@@ -335,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                 const uint32_t nlb = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(1)], (int)(gw * 32 + Q::slot_of(1) * 16));
                 const uint32_t nra = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(2)], (int)(gw * 32 + Q::slot_of(2) * 16));
                 const uint32_t nrb = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(3)], (int)(gw * 32 + Q::slot_of(3) * 16));
-                if (nla == 0 || nlb == 0 || nra == 0 || nrb == 0) continue;      // an empty half: nothing survives
+                if (nla * nlb * nra * nrb == 0) continue;                        // an empty half: nothing survives  (each <= 64)
                 const uint2* cw = child + gw * Q::CW;
                 const uint2 *la = cw + Q::node(0).OFF, *lb = cw + Q::node(1).OFF, *ra = cw + Q::node(2).OFF, *rb = cw + Q::node(3).OFF;
                 const float eps_l = thr[w * Q::TH_F], eps_r = thr[w * Q::TH_F + 1];
@@ -345,8 +395,8 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                 if (tl <= 64 && tr <= 64) {
                     // both half joins in one step
                     const float rnl = __builtin_amdgcn_rcpf((float)nlb), rnr = __builtin_amdgcn_rcpf((float)nrb);   // (1 ulp: ample for div_small)
-                    const uint32_t il = div_small(lane_h, rnl), jl = lane - __umul24(il, nlb);
-                    const uint32_t ir = div_small(lane_h, rnr), jr = lane - __umul24(ir, nrb);
+                    const uint32_t il = div_small(lane_h, rnl), jl = (uint32_t)(__mul24((int)il, -(int)nlb) + (int)lane);
+                    const uint32_t ir = div_small(lane_h, rnr), jr = (uint32_t)(__mul24((int)ir, -(int)nrb) + (int)lane);
                     // lanes past a half's candidates read the entries that follow in LDS and are masked out of the ballots
                     const uint2 a0 = la[il], b0 = lb[jl], a1 = ra[ir], b1 = rb[jr];
                     const float s0 = __uint_as_float(a0.y) + __uint_as_float(b0.y);          // :90
@@ -358,18 +408,21 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                     if (p1) rp[mbcnt(h1)] = make_uint2(a1.x * Q::FRB + b1.x, __float_as_uint(s1));
                     nL = (uint32_t)__popcll(h0); nR = (uint32_t)__popcll(h1);
                 } else {
-                    nL = join_to_list(la, nla, lb, nlb, eps_l, Q::FLB * mulR, lp, CAPL);
-                    nR = nL == LIST_OVERFLOW || nL == 0 ? nL : join_to_list(ra, nra, rb, nrb, eps_r, Q::FRB, rp, CAPR);
+                    // (the list lengths are wave-uniform by construction; without the readfirstlane the branches below count as
+                    //  divergent, and every value carried around this loop -- the appender's state -- is then held in VGPRs)
+                    nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)join_to_list(la, nla, lb, nlb, eps_l, Q::FLB * mulR, lp, CAPL));
+                    nR = nL == LIST_OVERFLOW || nL == 0 ? nL : (uint32_t)__builtin_amdgcn_readfirstlane((int)join_to_list(ra, nra, rb, nrb, eps_r, Q::FRB, rp, CAPR));
                     if (nL == LIST_OVERFLOW || nR == LIST_OVERFLOW) {
                         if (lane == 0) {
                             const uint32_t qi = atomicAdd(p.ovf_count, 1u);
                             p.ovf_queue[qi] = ((unsigned long long)mat << 32) | (unsigned long long)(t0 + w);
                         }
+                        // (keeps the join of the one-lane branch out of the loop latch: a phi there that also merges other paths
+                        //  would count as divergent, and with it every value carried around the loop -- see RowAppender::roll)
+                        __builtin_amdgcn_wave_barrier();
                         continue;
                     }
                 }
-                nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)nL);          // wave-uniform by construction: keep them scalar
-                nR = (uint32_t)__builtin_amdgcn_readfirstlane((int)nR);
                 if (nL == 0 || nR == 0) continue;
                 wave_lds_sync();
                 if (p.flags & 4u) { emitted += nL + nR; continue; }                 // diagnostics: list building only
@@ -394,17 +447,17 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                     auto trip = [&](auto NSC, auto FULLC, uint32_t i0) {
                         constexpr int NS = decltype(NSC)::value;
                         constexpr bool FULL = decltype(FULLC)::value;
-                        uint2 a[NS]; float s[NS]; bool pass[NS], live[NS]; uint64_t m[NS]; uint64_t any = 0;
+                        uint2 a[NS]; float s[NS]; bool live[NS]; uint64_t m[NS]; uint64_t any = 0;
 #pragma unroll
                         for (int u = 0; u < NS; ++u) a[u] = ap[i0 + u * rps];
 #pragma unroll
                         for (int u = 0; u < NS; ++u) {
                             s[u] = __uint_as_float(a[u].y) + by;                     // pk_compute.cpp:90
                             const bool c = s[u] > eps;                               // :91
-                            if constexpr (FULL) { live[u] = lane_ok; pass[u] = lane_ok && c; m[u] = okmask & ballot64(c); }
+                            if constexpr (FULL) { live[u] = lane_ok; m[u] = okmask & ballot64(c); }
                             else {
                                 const uint32_t nv = min(rps, nL - i0 - u * rps) * nRb;   // live lanes of the step
-                                live[u] = lane < nv; pass[u] = live[u] && c; m[u] = ballot64(live[u]) & ballot64(c);
+                                live[u] = lane < nv; m[u] = ballot64(live[u]) & ballot64(c);
                             }
                             any |= m[u];
                         }
@@ -414,29 +467,37 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                             for (int u = 0; u < NS; ++u) emitted += (uint32_t)__popcll(m[u]);
                             return;
                         } else {
-                        uint32_t rank[NS], bk[NS]; unsigned long long got[NS];
+                        uint32_t rank[NS], bk[NS], rc[NS]; unsigned long long got[NS];
 #pragma unroll
                         for (int u = 0; u < NS; ++u) {
                             const uint32_t xl = (uint32_t)m[u] & rm_lo, xh = (uint32_t)(m[u] >> 32) & rm_hi;
                             rank[u] = __builtin_amdgcn_mbcnt_hi(xh, __builtin_amdgcn_mbcnt_lo(xl, 0u));
-                            const uint32_t rc = (uint32_t)__popc(xl) + (uint32_t)__popc(xh);
+                            rc[u] = (uint32_t)__popc(xl) + (uint32_t)__popc(xh);
                             bk[u] = a[u].x / TBL;
                             asm volatile("" : "=v"(got[u]));                         // only the head lanes' values are read (bpermute below)
-                            if (is_head && live[u]) got[u] = atomicAdd(&app.st[bk[u]], (unsigned long long)rc);
                         }
-                        uint32_t v[NS]; uint2 val[NS]; bool over[NS]; uint64_t ovf[NS]; uint64_t anyo = 0;
+                        if constexpr (FULL) {                                        // one exec region for the steps' reservations
+                            if (is_head) {
+#pragma unroll
+                                for (int u = 0; u < NS; ++u) got[u] = atomicAdd(&app.st[bk[u]], (unsigned long long)rc[u]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < NS; ++u)
+                                if (is_head && live[u]) got[u] = atomicAdd(&app.st[bk[u]], (unsigned long long)rc[u]);
+                        }
+                        uint32_t v[NS]; uint2 val[NS]; uint64_t ovf[NS]; uint64_t anyo = 0;
 #pragma unroll
                         for (int u = 0; u < NS; ++u) {
                             const uint32_t fill = (uint32_t)__builtin_amdgcn_ds_bpermute(head_addr, (int)(uint32_t)got[u]);
-                            const uint32_t cb = (uint32_t)__builtin_amdgcn_ds_bpermute(head_addr, (int)(uint32_t)(got[u] >> 32));
+                            const uint32_t where = (uint32_t)__builtin_amdgcn_ds_bpermute(head_addr, (int)(uint32_t)(got[u] >> 32));
                             v[u] = fill + rank[u];
                             val[u] = make_uint2(a[u].x + b.x, __float_as_uint(s[u]));
                             const bool in = v[u] < CH;
-                            if (pass[u] && in) { if (st_ok) pool_store(p.pool, cb, v[u], val[u]); }
-                            const bool oc = v[u] >= CH;
-                            over[u] = pass[u] && oc;
-                            ovf[u] = m[u] & ballot64(oc);
+                            const uint64_t bin = ballot64(in);
+                            ovf[u] = m[u] & ~bin;
                             anyo |= ovf[u];
+                            pool_store_lanes(app.base, lshl3_add(v[u], where), val[u], m[u] & bin);
                         }
                         while (anyo) {                                                // a bucket's chunk filled up: open a new one
                             uint32_t bb = 0;
@@ -444,12 +505,12 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
 #pragma unroll
                             for (int u = 0; u < NS; ++u)
                                 if (!found && ovf[u]) { bb = (uint32_t)__builtin_amdgcn_readlane((int)bk[u], (int)(__ffsll((long long)ovf[u]) - 1)); found = true; }
-                            const uint32_t nid = app.roll(bb);
+                            const uint32_t nwhere = app.roll(bb);
                             anyo = 0;
 #pragma unroll
                             for (int u = 0; u < NS; ++u) {
-                                const bool h = over[u] && bk[u] == bb;
-                                if (h) { if (st_ok) pool_store(p.pool, nid, v[u] - CH, val[u]); }
+                                const bool h = ((ovf[u] >> lane) & 1ull) != 0 && bk[u] == bb;
+                                if (h) pool_store(app.base, nwhere + ((v[u] - CH) << 3), val[u]);
                                 ovf[u] &= ~ballot64(h);
                                 anyo |= ovf[u];
                             }

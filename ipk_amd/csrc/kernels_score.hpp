@@ -297,7 +297,8 @@ struct StreamParams {
     unsigned long long* ovf_queue;
     uint32_t* ovf_count;
     const uint32_t* mat_slot;      // [n_mats] group slot of a matrix inside the batch (big-list kernel)
-    uint32_t flags;                // diagnostics: bit 0 = skip the pool stores, bit 1 = skip the append bookkeeping too
+    uint32_t flags;                // diagnostics: bit 0 = skip the pool stores, bit 1 = skip the append bookkeeping too,
+                                   // bit 2 = list building only, bit 3 = quad kernel rebases its store window every 8 chunks
 };
 
 // M with floor(t / n) == (t * M) >> 16 for 0 <= t < 128, 1 <= n <= 64   (M = ceil(65536 / n))

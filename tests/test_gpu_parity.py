@@ -326,3 +326,28 @@ def test_large_pair_pool_matches_small_batches(engine):
     keys, scores, _ = co.explore_group(mats[2 * 137:2 * 137 + 2], k, eps)
     a, b = int(offsets[137]), int(offsets[138])
     assert np.array_equal(bk[a:b], keys) and np.array_equal(bs[a:b].view(np.uint32), scores.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [8, 10, 12])
+def test_quad_store_window_rebasing(engine, k):
+    """The quad kernel stores pairs through 32-bit offsets from a per-wavefront base chunk and moves the base when a new
+    chunk lies 4 GiB past it; debug_flags bit 3 shrinks that span to 8 chunks, so every wavefront rebases many times:
+    same sets and scored counts as the oracle, also when the pool is too small at first (the retry path)."""
+    mats = synth_matrices(6, 700, 4, 0.1, 99 + k)
+    groups = np.array([0, 0, 1, 1, 2, 2], dtype=np.uint32)
+    eps = co.log_threshold(1.5, 4, k)
+    ref = [co.explore_group(mats[groups == g], k, eps) for g in range(3)]
+    for pool_chunks in (0, 40):
+        engine.set_option("debug_flags", 8)
+        engine.set_option("debug_pool_chunks", pool_chunks)
+        try:
+            res = engine.score_groups(mats, groups, k, eps)
+        finally:
+            engine.set_option("debug_flags", 0)
+            engine.set_option("debug_pool_chunks", 0)
+        for g in range(3):
+            gk, gs = res.group(g)
+            assert np.array_equal(gk, ref[g][0]) and np.array_equal(gs.view(np.uint32), ref[g][1].view(np.uint32)), (k, pool_chunks, g)
+        assert res.emitted == sum(r[2] for r in ref)
+        res.free()
