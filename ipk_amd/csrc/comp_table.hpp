@@ -9,6 +9,7 @@ namespace ipkgpu {
 struct CompTable {
     const uint32_t* mask;      // [groups][mask_words]
     const uint32_t* rank;      // [groups][mask_words / 2]
+    const uint64_t* vaddr;     // [groups][mask_words / 2]: address of the block's first value (= values(g, b) + rank)
     const uint2* pool;         // values of (g, b) start at (u32*)(pool + off[(g * NB + b) * stride])
     const uint64_t* off;
     uint64_t mask_words;

@@ -44,6 +44,9 @@ __host__ __device__ __forceinline__ uint32_t dec_score_bits(uint32_t e)
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// llvm.amdgcn.ballot on the i1 itself: HIP's __ballot() goes through an int and costs two extra VALU instructions
+// (v_cndmask + v_cmp) wherever the predicate is a combination of compares
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

@@ -75,7 +75,7 @@ struct ipkgpu_ctx {
     uint64_t mask_words = 0;     // 2 * ceil(table_size / 64): rows padded to whole 64-slot blocks
     // compressed table form (exact-partition variant on sparse key spaces; comp_table.hpp): no dense ctx->table
     bool table_compressed = false;
-    DevBuf rank, ucnt;
+    DevBuf rank, vaddr, ucnt, qpack;
     uint32_t comp_nb = 0, comp_stride = 0, comp_tbl = 0;
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
     double acc_main_ms = 0, acc_reduce_ms = 0;   // dominant scoring kernel / LDS reduce pass of the current call
@@ -291,7 +291,7 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
                       &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
                       &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->mask,
-                      &ctx->rank, &ctx->ucnt, &ctx->ptrs};
+                      &ctx->rank, &ctx->vaddr, &ctx->ucnt, &ctx->qpack, &ctx->ptrs};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
     ipkgpu_comm_release(ctx);
@@ -579,7 +579,7 @@ int launch_xp_reduce(ipkgpu_ctx* ctx, uint32_t n_gb, uint32_t S, uint64_t T, con
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(), off, S, NB, T, table,
-                           ctx->mask.as<uint32_t>(), ctx->mask_words, ctx->rank.as<uint32_t>(), ctx->ucnt.as<uint32_t>());
+                           ctx->mask.as<uint32_t>(), ctx->mask_words, ctx->rank.as<uint32_t>(), ctx->vaddr.as<uint64_t>(), ctx->ucnt.as<uint32_t>());
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
     }
@@ -752,10 +752,16 @@ uint32_t xp_bucket_slots(uint32_t sigma, uint32_t k)
 #undef M_XT
     return 0;
 }
+#define KM_LAUNCH(KERN, CAPV, ...)                                                                                        \
+    do {                                                                                                                  \
+        if (P == 1) hipLaunchKernelGGL((KERN<true, CAPV>), dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERN<false, CAPV>), dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream, __VA_ARGS__);     \
+    } while (0)
+
 CompTable comp_table(const ipkgpu_ctx* ctx)
 {
     CompTable ct;
-    ct.mask = ctx->mask.as<uint32_t>(); ct.rank = ctx->rank.as<uint32_t>(); ct.pool = ctx->pool.as<uint2>();
+    ct.mask = ctx->mask.as<uint32_t>(); ct.rank = ctx->rank.as<uint32_t>(); ct.vaddr = ctx->vaddr.as<uint64_t>(); ct.pool = ctx->pool.as<uint2>();
     ct.off = ctx->gboff.as<uint64_t>(); ct.mask_words = ctx->mask_words;
     ct.NB = ctx->comp_nb; ct.stride = ctx->comp_stride; ct.TBL = ctx->comp_tbl;
     return ct;
@@ -900,7 +906,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
             return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool (%llu pairs) does not fit device memory (lower workspace_bytes to score fewer groups per batch)",
                         (unsigned long long)total);
     }
-    RC_TRY(ensure(ctx, ctx->pool, std::max<uint64_t>(total, 1) * 8));
+    RC_TRY(ensure(ctx, ctx->pool, std::max<uint64_t>(total, 1) * 8 + 256));     // (+256: km_write_c_kernel reads up to 32 values from a row's start)
     sp.pool = ctx->pool.as<uint2>();
     const int ev_c = sw.mark();
     RC_TRY(dispatch_xp(ctx, pl.sigma, pl.k, xp, gb * S, true));
@@ -909,6 +915,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     const int ev_d = sw.mark();
     if (compress) {
         RC_TRY(ensure(ctx, ctx->rank, (size_t)gb * (ctx->mask_words / 2) * 4));
+        RC_TRY(ensure(ctx, ctx->vaddr, (size_t)gb * (ctx->mask_words / 2) * 8));
         RC_TRY(ensure(ctx, ctx->ucnt, n_gb * 4));
     } else {
         RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 4));
@@ -1064,7 +1071,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const uint64_t expected_chunks = (uint64_t)((double)windows * ppw_est / CH);
     const uint64_t max_wg = std::max<uint64_t>(slots, expected_chunks / 2 / ((uint64_t)SNW * NBK * SUB));
     // whole rounds of resident workgroups: a partial last round leaves CUs idle for a full workgroup's run time
-    const uint64_t rounds = std::max<uint64_t>(1, std::min<uint64_t>(8, max_wg / slots));
+#ifndef IPK_ROUNDS
+#define IPK_ROUNDS 8
+#endif
+    const uint64_t rounds = std::max<uint64_t>(1, std::min<uint64_t>(IPK_ROUNDS, max_wg / slots));
     uint64_t S64 = std::max<uint64_t>(1, (slots * rounds) / gb);
     uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(S64, s_tiles_per_mat));
     const uint32_t n_wg = gb * S;
@@ -1680,12 +1690,18 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         Batch& b = batches.back();
         HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.counts, n_slots_all * 4));
         HIP_TRY(ctx, hipMemsetAsync(b.counts, 0, n_slots_all * 4, ctx->stream));
+        // compressed tables of up to 256 groups go through the fast key-major writer, which wants the rows counted per quarter
+        uint32_t* qpack = nullptr;
+        if (ctx->table_compressed && gb <= 256 && 64ull * (ctx->mask_words / 2) * 8 < (1ull << 32)) {
+            RC_TRY(ensure(ctx, ctx->qpack, n_slots_all * 4));
+            qpack = ctx->qpack.as<uint32_t>();
+        }
         if (ctx->mask_valid && (T + 31) / 32 >= (uint64_t)ctx->num_cu * 1024)      // a thread per mask word fills the chip
             hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)(((T + 31) / 32 + 255) / 256)), dim3(256), 0, ctx->stream,
-                               ctx->mask.as<uint32_t>(), ctx->mask_words, T, gb, P, slots, b.counts);
+                               ctx->mask.as<uint32_t>(), ctx->mask_words, T, gb, P, slots, b.counts, qpack);
         else if (ctx->mask_valid)
             hipLaunchKernelGGL(km_count_mask_key_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
-                               ctx->mask.as<uint32_t>(), ctx->mask_words, T, gb, P, slots, b.counts);
+                               ctx->mask.as<uint32_t>(), ctx->mask_words, T, gb, P, slots, b.counts, qpack);
         else
             hipLaunchKernelGGL(km_count_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
                                ctx->table.as<uint32_t>(), T, gb, P, slots, b.counts);
@@ -1704,9 +1720,13 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         const int km0 = sw.mark();
         if (ctx->table_compressed) {
             const uint64_t per_xcd = (((T + 63) / 64) + 7) / 8;
-            hipLaunchKernelGGL(km_write_c_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
-                               comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
-                               ctx->offsets.as<uint64_t>(), b.entries);
+            if (qpack)
+                KM_LAUNCH(km_write_c_kernel, KMC_CAP, comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots, b.counts,
+                          qpack, ctx->offsets.as<uint64_t>(), b.entries);
+            else
+                hipLaunchKernelGGL(km_write_c_generic_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
+                                   comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
+                                   ctx->offsets.as<uint64_t>(), b.entries);
         } else
             hipLaunchKernelGGL(km_write_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
                                ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,

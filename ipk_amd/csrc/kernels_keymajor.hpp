@@ -12,6 +12,7 @@
 //
 // Everything is a coalesced sweep of the dense tables: no sort, no global atomics.
 #pragma once
+#include <type_traits>
 #include "dcla_device.hpp"
 #include "comp_table.hpp"
 
@@ -41,17 +42,22 @@ __global__ __launch_bounds__(256) void km_count_kernel(const uint32_t* __restric
 // successive groups are added into eight bit planes (a ripple-carry add of a 1-bit number: 16 logic operations for
 // 32 keys), emptied into the 32 per-key totals every 255 groups.
 __global__ __launch_bounds__(256) void km_count_mask_kernel(const uint32_t* __restrict__ mask, uint64_t W, uint64_t T,
-                                                            uint32_t G, uint32_t P, uint64_t slots, uint32_t* __restrict__ counts)
+                                                            uint32_t G, uint32_t P, uint64_t slots, uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ qpack)
 {
     const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (w * 32 >= T) return;
     uint32_t plane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t total[32];
+    uint32_t total[32], pack[32];
 #pragma unroll
-    for (int b = 0; b < 32; ++b) total[b] = 0;
+    for (int b = 0; b < 32; ++b) { total[b] = 0; pack[b] = 0; }
     const uint32_t* m = mask + w;
-    for (uint32_t g0 = 0; g0 < G; g0 += 255) {
-        const uint32_t g1 = min(G, g0 + 255u);
+    // qpack (G <= 256): the rows are also counted per quarter of ceil(G / 4) rows -- byte q of qpack[key] = rows of quarter q
+    // that hold the key (what km_write_c_kernel's four wavefronts start from); otherwise chunks of 255 rows (8 bit planes)
+    const uint32_t step = qpack ? (G + 3) / 4 : 255u;
+    uint32_t q = 0;
+    for (uint32_t g0 = 0; g0 < G; g0 += step, ++q) {
+        const uint32_t g1 = min(G, g0 + step);
         for (uint32_t g = g0; g < g1; ++g) {
             uint32_t carry = m[(size_t)g * W];
 #pragma unroll
@@ -63,6 +69,7 @@ __global__ __launch_bounds__(256) void km_count_mask_kernel(const uint32_t* __re
 #pragma unroll
             for (int p = 0; p < 8; ++p) c |= ((plane[p] >> b) & 1u) << p;
             total[b] += c;
+            pack[b] |= c << ((8u * q) & 31u);
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) plane[p] = 0;
@@ -70,27 +77,40 @@ __global__ __launch_bounds__(256) void km_count_mask_kernel(const uint32_t* __re
 #pragma unroll
     for (int b = 0; b < 32; ++b) {
         const uint64_t x = w * 32 + b;
-        if (x < T) counts[(x % P) * slots + x / P] = total[b];
+        if (x < T) {
+            const uint64_t idx = (x % P) * slots + x / P;
+            counts[idx] = total[b];
+            if (qpack) qpack[idx] = pack[b];
+        }
     }
 }
 
 // One thread per key: for key spaces too small to fill the chip with one thread per mask word (DNA k <= 11).
 __global__ __launch_bounds__(256) void km_count_mask_key_kernel(const uint32_t* __restrict__ mask, uint64_t W, uint64_t T,
-                                                                uint32_t G, uint32_t P, uint64_t slots, uint32_t* __restrict__ counts)
+                                                                uint32_t G, uint32_t P, uint64_t slots, uint32_t* __restrict__ counts,
+                                                                uint32_t* __restrict__ qpack)
 {
     const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (x >= T) return;
     const uint32_t* m = mask + (x >> 5);
     const uint32_t sh = (uint32_t)x & 31u;
-    uint32_t c = 0, g = 0;
-    for (; g + 4 <= G; g += 4) {
-        const uint32_t v0 = m[(size_t)(g + 0) * W], v1 = m[(size_t)(g + 1) * W];
-        const uint32_t v2 = m[(size_t)(g + 2) * W], v3 = m[(size_t)(g + 3) * W];
-        c += ((v0 >> sh) & 1u) + ((v1 >> sh) & 1u) + ((v2 >> sh) & 1u) + ((v3 >> sh) & 1u);
+    const uint32_t step = qpack ? (G + 3) / 4 : G;          // (per-quarter counts: see km_count_mask_kernel)
+    uint32_t total = 0, pack = 0, q = 0;
+    for (uint32_t g0 = 0; g0 < G; g0 += step, ++q) {
+        const uint32_t g1 = min(G, g0 + step);
+        uint32_t c = 0, g = g0;
+        for (; g + 4 <= g1; g += 4) {
+            const uint32_t v0 = m[(size_t)(g + 0) * W], v1 = m[(size_t)(g + 1) * W];
+            const uint32_t v2 = m[(size_t)(g + 2) * W], v3 = m[(size_t)(g + 3) * W];
+            c += ((v0 >> sh) & 1u) + ((v1 >> sh) & 1u) + ((v2 >> sh) & 1u) + ((v3 >> sh) & 1u);
+        }
+        for (; g < g1; ++g) c += (m[(size_t)g * W] >> sh) & 1u;
+        total += c;
+        pack |= c << ((8u * q) & 31u);
     }
-    for (; g < G; ++g) c += (m[(size_t)g * W] >> sh) & 1u;
-    const uint64_t o = x % P, q = x / P;
-    counts[o * slots + q] = c;
+    const uint64_t idx = (x % P) * slots + x / P;
+    counts[idx] = total;
+    if (qpack) qpack[idx] = pack;
 }
 
 // ---- generic exclusive scan of u32 -> u64 (three kernels) -------------------------------------
@@ -184,10 +204,13 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
     }
 }
 
-// km_write_kernel reading the compressed form.  Workgroup w takes key block (w % 8) * ceil(blocks / 8) + w / 8:
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+// km_write_kernel reading the compressed form: the generic version (any number of groups; km_write_c_kernel below is the fast
+// one for up to 256 groups per batch).  Workgroup w takes key block (w % 8) * ceil(blocks / 8) + w / 8:
 // workgroups are dealt round-robin to the 8 XCDs, so each XCD walks one contiguous range of key blocks and the mask /
 // rank lines (eight / sixteen blocks per 64-byte line) are shared in its L2.
-__global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t T, uint32_t G,
+__global__ __launch_bounds__(256) void km_write_c_generic_kernel(CompTable ct, uint64_t T, uint32_t G,
                                                          const uint32_t* __restrict__ branch_of_group, uint32_t P,
                                                          uint64_t slots, uint64_t* __restrict__ cursor,
                                                          uint2* __restrict__ entries)
@@ -245,6 +268,176 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
         const uint64_t x = x0 + threadIdx.x;
         if (x < T) cursor[(x % P) * slots + x / P] = run[threadIdx.x];
     }
+}
+
+// A load of read-only data at a wave-uniform address: through the constant address space, so that it becomes a scalar load
+// (s_load_*: no vector instruction, the result lands in scalar registers) -- for data a PREVIOUS kernel wrote.
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T* p)
+{
+    return *(const __attribute__((address_space(4))) T*)(uintptr_t)(p);      // (via the integer: no generic -> constant cast exists)
+}
+// the LDS byte address of a __shared__ object (for ds_* instructions written by hand)
+__device__ __forceinline__ uint32_t lds_address(const void* p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)(p);
+}
+
+// dec_score_bits without a select (the select form inside the copy loops below crashes this compiler's instruction selection)
+__device__ __forceinline__ uint32_t dec_score_bits_bf(uint32_t e) { return e ^ ~((uint32_t)((int32_t)e >> 31) >> 1); }
+
+constexpr uint32_t KMC_CAP = 5632;       // entries of a key block staged in LDS at once (44 KiB + 6 KiB of row data: three workgroups per CU)
+
+// km_write_kernel reading the compressed form, for batches of up to 256 groups.  Workgroup w takes key block
+// (w % 8) * ceil(blocks / 8) + w / 8: workgroups are dealt round-robin to the 8 XCDs, so each XCD walks one contiguous range
+// of key blocks and the lines of the occupancy bits / value addresses (eight blocks per 64-byte line) are shared in its L2.
+//
+// The work is a transposition: the values of a (group, block) are contiguous in memory in KEY order, a key's entries are
+// contiguous in the output in GROUP order.  The round-2 profile of the tile version (km_write_c_generic_kernel: a 64 x 64
+// tile in LDS per 64 groups, two barriers per tile) showed it bound by instruction issue and by the latency of three small
+// scattered loads per row, at 1.2x the algorithmic HBM bytes but a quarter of the bandwidth.  This version spends ~5 vector
+// instructions per ROW and keeps a wavefront's 64 value loads in flight together:
+//   rows     one (group, block) row at a time with the 64 KEYS across the lanes: the row's occupancy bits and the address of
+//            its values are wave-uniform (scalar loads), lane x's value is values[popcount(bits below x)] -- one coalesced load;
+//   scatter  the entry goes to LDS at (key's offset in the block's output) + (groups before this one that hold the key):
+//            a per-lane running position, advanced under exec = the row's bits (written to exec directly: no compares);
+//   split    the four wavefronts take a quarter of the rows each (<= 64); where each starts, per key, comes from the
+//            per-quarter counts the counting kernel leaves in qpack;
+//   copy     the staged block leaves as one linear, fully coalesced copy (scores decoded here, where all lanes are busy).
+// A block whose entries exceed the LDS stage is done in several key ranges (greedy split at key boundaries).
+template <bool ONE_OWNER, uint32_t CAP>
+__global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t T, uint32_t G,
+                                                         const uint32_t* __restrict__ branch_of_group, uint32_t P,
+                                                         uint64_t slots, const uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ qpack,
+                                                         uint64_t* __restrict__ cursor, uint2* __restrict__ entries)
+{
+    __shared__ uint2 out[CAP];
+    __shared__ uint4 rowmeta[4][64];                         // per wavefront and row: occupancy bits, address of the values
+    __shared__ uint32_t rowbr[4][64];                        //                        branch id
+    __shared__ uint32_t kpre[65];                            // exclusive prefix of the block's per-key entry counts
+    __shared__ uint64_t kcur[64];                            // the keys' output positions
+    const uint64_t nblocks = (T + 63) / 64, per_xcd = (nblocks + 7) / 8;
+    const uint64_t kb = (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || kb >= nblocks) return;
+    const uint64_t x0 = kb * 64;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+
+    // this lane's key: where it lives, and how many rows of the quarters before this wavefront's hold it
+    const uint64_t x = x0 + lane;
+    const size_t cidx = x < T ? (ONE_OWNER ? (size_t)x : (size_t)((x % P) * slots + x / P)) : 0;
+    const uint32_t qp = x < T ? qpack[cidx] : 0u;
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 3; ++w) before += w < wave ? (qp >> (8u * w)) & 0xFFu : 0u;
+    uint32_t my_cnt = 0;
+    if (threadIdx.x < 64) {
+        uint64_t cur = 0;
+        if (x < T) { my_cnt = counts[cidx]; cur = cursor[cidx]; }
+        kcur[threadIdx.x] = cur;
+        uint32_t inc = my_cnt;
+        for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+        kpre[threadIdx.x + 1] = inc;
+        if (threadIdx.x == 0) kpre[0] = 0;
+    }
+
+    // this wavefront's rows [r0, r0 + nrows), nrows <= 64.  Their occupancy bits, value addresses and branch ids come in with
+    // ONE coalesced-as-can-be load each (lane = row) and are staged in LDS, from where every row's are read back as broadcasts:
+    // the per-row values are wave-uniform without a chain of scalar-load round trips (a first version that fetched them with
+    // s_load, eight rows at a time, spent its time waiting for those).
+    const uint32_t rq = (G + 3) / 4, r0 = min(G, wave * rq), nrows = min(G, r0 + rq) - r0;
+    {
+        const uint32_t row_bytes = (uint32_t)(ct.mask_words / 2) * 8u;                   // a row of bits / of addresses
+        const bool live = lane < nrows;
+        const size_t ro = (size_t)(r0 + (live ? lane : 0u)) * row_bytes;
+        uint64_t m = 0, va = reinterpret_cast<uint64_t>(ct.pool);                        // (rows past the end: no bits, any readable address)
+        uint32_t br = 0;
+        if (live) {
+            m = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(reinterpret_cast<const uint64_t*>(ct.mask) + kb) + ro);
+            va = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(ct.vaddr + kb) + ro);
+            br = branch_of_group[r0 + lane];
+        }
+        rowmeta[wave][lane] = make_uint4((uint32_t)m, (uint32_t)(m >> 32), (uint32_t)va, (uint32_t)(va >> 32));
+        rowbr[wave][lane] = br;
+    }
+    // the value loads of all rows, none waited for here.  Every lane loads: a lane without the key reads the value of the next
+    // key that has one (or, past the row's end, whatever follows it in the pool, which is allocated 256 B longer for this) and
+    // does not store it.
+    uint32_t val[64];
+#pragma unroll
+    for (uint32_t b8 = 0; b8 < 64; b8 += 8) {
+        if (b8 < nrows) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint4 mv = rowmeta[wave][b8 + u];                                  // (same address in every lane: a broadcast read)
+                const uint32_t j = __builtin_amdgcn_mbcnt_hi(mv.y, __builtin_amdgcn_mbcnt_lo(mv.x, 0u));
+                const uint32_t* vals = reinterpret_cast<const uint32_t*>(((uint64_t)mv.w << 32) | mv.z);
+                val[b8 + u] = __builtin_nontemporal_load(vals + j);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t out_lds = lds_address(out);
+
+    for (uint32_t ka = 0; ka < 64;) {
+        // the key range [ka, ke) of this round: as many keys as fit the stage
+        const uint32_t pre_a = kpre[ka];
+        const uint32_t fits = (uint32_t)__popcll(ballot64(lane >= ka && kpre[lane + 1] - pre_a <= CAP));
+        const uint32_t ke = ka + max(fits, 1u);                                         // (G <= CAP: one key always fits)
+        const uint32_t n_part = kpre[ke] - pre_a;
+        if (n_part == 0) { ka = ke; continue; }
+        const uint64_t pm = (ke >= 64 ? ~0ull : ((1ull << ke) - 1ull)) & ~((1ull << ka) - 1ull);
+        const uint32_t pm_lo = (uint32_t)pm, pm_hi = (uint32_t)(pm >> 32);
+
+        // the rows' entries into the stage  (lanes outside the range never store)
+        uint32_t posb = out_lds + (kpre[lane] - pre_a + before) * 8u;
+#pragma unroll
+        for (uint32_t b8 = 0; b8 < 64; b8 += 8) {
+            if (b8 < nrows) {
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint2 mm = *reinterpret_cast<const uint2*>(&rowmeta[wave][b8 + u]);
+                    u32x2_t e; e.x = rowbr[wave][b8 + u]; e.y = val[b8 + u];
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mm.x & pm_lo));
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mm.y & pm_hi));
+                    asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, -1"
+                                 : "+v"(posb) : "v"(e), "s"(((uint64_t)hi << 32) | lo));
+                }
+            }
+        }
+        __syncthreads();
+
+        // copy out
+        bool linear = ONE_OWNER;
+        if (ONE_OWNER) {                                     // (a fresh scan makes consecutive keys adjacent; checked, not assumed)
+            const bool ok = lane < ka || lane + 1 >= ke || kcur[lane] + (kpre[lane + 1] - kpre[lane]) == kcur[lane + 1];
+            linear = ballot64(ok) == ~0ull;
+        }
+        if (linear) {
+            uint2* dst = entries + kcur[ka];
+#pragma unroll 2
+            for (uint32_t i = threadIdx.x; i < n_part; i += 256) {
+                uint2 e = out[i];
+                e.y = dec_score_bits_bf(e.y);
+                dst[i] = e;
+            }
+        } else {
+            for (uint32_t t = ka + wave; t < ke; t += 4) {
+                const uint32_t n = kpre[t + 1] - kpre[t];
+                const uint2* src = out + (kpre[t] - pre_a);
+                uint2* dst = entries + kcur[t];
+                for (uint32_t i = lane; i < n; i += 64) {
+                    uint2 e = src[i];
+                    e.y = dec_score_bits_bf(e.y);
+                    dst[i] = e;
+                }
+            }
+        }
+        ka = ke;
+        if (ka < 64) __syncthreads();                        // the stage is reused
+    }
+    // the advanced cursors (batches of groups append in order)
+    if (threadIdx.x < 64 && x < T) cursor[cidx] = kcur[threadIdx.x] + my_cnt;
 }
 
 // ---- merge of S sources for one owner -----------------------------------------------------------

@@ -25,10 +25,6 @@
 
 namespace ipkgpu {
 
-// llvm.amdgcn.ballot on the i1 itself: HIP's ballot64() goes through an int and costs two extra VALU instructions
-// (v_cndmask + v_cmp) wherever the predicate is a combination of compares
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-
 // The four child nodes of a window: LA = (0, LA), LB = (LA, LB), RA = (HL, RA), RB = (HL + RA, RB), each of 2 or 3 symbols.
 // A wavefront evaluates them for TWO windows at a time in 16-lane slots: slot = (window half, node of the step), so a
 // step runs two nodes of equal size side by side (k = 10: step 0 = LA | RA, step 1 = LB | RB).
@@ -461,7 +457,9 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                             }
                             any |= m[u];
                         }
+#ifndef IPK_QNOANY
                         if (any == 0) return;
+#endif
                         if constexpr (count_only) {                                   // the pool-sizing pre-pass
 #pragma unroll
                             for (int u = 0; u < NS; ++u) emitted += (uint32_t)__popcll(m[u]);

@@ -1082,13 +1082,14 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_xp_kernel(XpParams
 // table is kept as  occupancy bits (mask)  +  the non-empty slots' score codes in slot order, written in place over
 // the head of the (group, bucket) pool range just consumed (unique slots <= pairs)  +  per 64-slot block the number
 // of non-empty slots before it in the slice (rank).  Slot x of group g then sits at
-//   values(g, b)[rank[g][x / 64] + popcount(mask64[g][x / 64] & below(x % 64))],  b = x / TBL,
+//   values(g, b)[rank[g][x / 64] + popcount(mask64[g][x / 64] & below(x % 64))],  b = x / TBL   (vaddr[g][x / 64] = &values(g, b)[rank[g][x / 64]]),
 // values(g, b) = (u32*)(pool + off[(g * NB + b) * S]).  Consumers: km_write_c_kernel, write_chunks_c_kernel.
 template <uint32_t TBL, int NT, bool COMPRESS>
 __global__ __launch_bounds__(NT) void reduce_ranges_kernel(uint2* __restrict__ pool, const uint64_t* __restrict__ off,
                                                           uint32_t S, uint32_t NB, uint64_t T, uint32_t* __restrict__ table,
                                                           uint32_t* __restrict__ mask, uint64_t mask_words,
-                                                          uint32_t* __restrict__ rank, uint32_t* __restrict__ ucnt)
+                                                          uint32_t* __restrict__ rank, uint64_t* __restrict__ vaddr,
+                                                          uint32_t* __restrict__ ucnt)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
@@ -1150,15 +1151,24 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(uint2* __restrict__ p
         uint32_t* vals = reinterpret_cast<uint32_t*>(pool + r0);      // in place: every pair of the range has been consumed
         uint32_t* mrow = mask + (size_t)g * mask_words + (key0 >> 5);
         uint32_t* rrow = rank + (size_t)g * (mask_words / 2) + (key0 >> 6);
+        uint64_t* arow = vaddr + (size_t)g * (mask_words / 2) + (key0 >> 6);      // the block's first value, as an address (km_write_c_kernel)
+        // lane j collects block j's rank and bits; they leave as coalesced stores after the loop (BPW <= 64)
+        static_assert(BPW <= 64, "one lane per block of the wave");
+        uint32_t my_base = 0;
+        uint64_t my_m = 0;
 #pragma unroll
         for (uint32_t j = 0; j < BPW; ++j) {
             const uint32_t blk = b_lo + j;
             const uint64_t m = __ballot(vr[j] != 0u);
-            if (blk < b_hi) {
-                if (lane == 0) { rrow[blk] = base; mrow[2 * blk] = (uint32_t)m; mrow[2 * blk + 1] = (uint32_t)(m >> 32); }
-                if (vr[j] != 0u) vals[base + mbcnt(m)] = vr[j];
-            }
+            if (lane == j) { my_base = base; my_m = m; }
+            if (blk < b_hi && vr[j] != 0u) vals[base + mbcnt(m)] = vr[j];
             base += (uint32_t)__popcll(m);
+        }
+        if (b_lo + lane < b_hi) {
+            const uint32_t blk = b_lo + lane;
+            rrow[blk] = my_base;
+            *reinterpret_cast<uint2*>(mrow + 2 * blk) = make_uint2((uint32_t)my_m, (uint32_t)(my_m >> 32));
+            arow[blk] = (uint64_t)(vals + my_base);
         }
         if (threadIdx.x == 0) ucnt[gb] = all;
     }

@@ -7,6 +7,7 @@ taken as is (exact for 16-B/lane stores; the 8-B/lane pair stores of the scoring
 JSON).
 
 usage: pmc_traffic.py <fetch_csv> <write_csv> <workload> <out.json> <kernel-substring> [more substrings ...]
+(a substring may be several parts joined by '&': all must occur in the kernel name -- template instantiations)
 The first substring's kernel is also written at top level ("kernel", "hbm_bytes_per_launch"): bench.py reads that.
 """
 import csv
@@ -17,7 +18,7 @@ import sys
 def per_launch(path, counter, kernel_sub):
     vals = {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and all(part in r["Kernel_Name"] for part in kernel_sub.split("&")):
             vals.setdefault(r["Dispatch_Id"], 0.0)
             vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
     if not vals:

@@ -1,0 +1,6 @@
+for v in base noany r4 r12 r16; do
+  if [ $v = base ]; then unset IPKGPU_LIB; else export IPKGPU_LIB=$PWD/ipk_amd/_variants/v_$v.so; fi
+  timeout -k 10 120 python bench.py --steps 10 --warmup 3 --e2e 0 --cpu-groups 0 > gpurun_out/var_$v.json 2> gpurun_out/var_$v.err
+  python -c "
+import json; j=json.load(open('gpurun_out/var_$v.json')); print('$v', round(j['ms_per_step'],3), [(k['kernel'],round(k['avg_launch_ms'],3)) for k in j['roofline'].get('kernels')])"
+done
