@@ -325,10 +325,13 @@ constexpr int NW = 8;    // wavefronts per workgroup
 #ifndef IPK_QCAP
 #define IPK_QCAP 160
 #endif
+#ifndef IPK_AACAP
+#define IPK_AACAP 512
+#endif
 template <int SIGMA, int K> constexpr int fast_cap()
 {
     if (SIGMA == 4) return K <= 10 ? IPK_QCAP : 512;
-    return 512;
+    return IPK_AACAP;
 }
 
 template <int SIGMA, int K, bool POS = false>
@@ -508,7 +511,11 @@ int launch_quad_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
 }
 
 // ---- exact-partition variant (count -> scan -> write -> reduce), kernels_score.hpp ---------------------
-constexpr int XP_NW = 11, XP_TW = 128;   // 11 waves: what fits 160 KB of LDS at AA k=6 (12 with 64-window tiles measured equal)
+#ifndef IPK_XPNW
+#define IPK_XPNW 11
+#endif
+constexpr int XP_TW = 128;
+template <int SIGMA, int K> constexpr int xp_nw() { return SIGMA == 20 ? IPK_XPNW : 11; }   // 11 waves: what fits 160 KB of LDS at AA k=6 (12 with 64-window tiles measured equal)
 template <int SIGMA, int K> constexpr uint32_t xp_tbl()
 {
     if (SIGMA == 20 && K == 6) return 16000u;                           // 4000 buckets per group; 64 KB reduce tables: two workgroups per CU
@@ -524,7 +531,7 @@ template <int SIGMA, int K> size_t xp_lds() {
     else {
         constexpr int CAP = fast_cap<SIGMA, K>();
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
-        return TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * 4;
+        return TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)xp_nw<SIGMA, K>() * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * 4;
     }
 }
 template <int SIGMA, int K, bool WRITE>
@@ -535,13 +542,13 @@ int launch_xp(ipkgpu_ctx* ctx, const XpParams& xp, uint32_t n_wg)
     else {
         constexpr int CAP = fast_cap<SIGMA, K>();
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
-        constexpr size_t lds = TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * 4;
+        constexpr size_t lds = TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)xp_nw<SIGMA, K>() * stream_wave_scratch<SIGMA, K, CAP>() * 8 + (size_t)NB * 4;
         static_assert(lds <= 160 * 1024, "exact-partition LDS budget");
-        static_assert((TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)XP_NW * stream_wave_scratch<SIGMA, K, CAP>() * 8) % 8 == 0, "cursor alignment");
-        auto kern = score_xp_kernel<SIGMA, K, CAP, XP_TW, XP_NW, TBL, WRITE>;
+        static_assert((TileGeo<SIGMA, K, XP_TW>::HEAD_BYTES + (size_t)xp_nw<SIGMA, K>() * stream_wave_scratch<SIGMA, K, CAP>() * 8) % 8 == 0, "cursor alignment");
+        auto kern = score_xp_kernel<SIGMA, K, CAP, XP_TW, xp_nw<SIGMA, K>(), TBL, WRITE>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(XP_NW * 64), lds, ctx->stream, xp);
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(xp_nw<SIGMA, K>() * 64), lds, ctx->stream, xp);
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
     }
@@ -862,7 +869,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     (void)nb;
     const uint32_t tiles_per_mat = (pl.nwin + XP_TW - 1) / XP_TW;
     const size_t lds_bytes = xp_lds_bytes(pl.sigma, pl.k);
-    const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / XP_NW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+    const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / (pl.sigma == 20 ? IPK_XPNW : 11), (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
     const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
     // four rounds of resident workgroups balance the tail; a unit costs only its NB counters
     const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((slots * 4) / gb, tiles_per_mat));

@@ -389,22 +389,26 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
         const uint64_t pm = (ke >= 64 ? ~0ull : ((1ull << ke) - 1ull)) & ~((1ull << ka) - 1ull);
         const uint32_t pm_lo = (uint32_t)pm, pm_hi = (uint32_t)(pm >> 32);
 
-        // the rows' entries into the stage  (lanes outside the range never store)
+        // the rows' entries into the stage  (lanes outside the range never store; a whole block needs no masking)
         uint32_t posb = out_lds + (kpre[lane] - pre_a + before) * 8u;
+        auto scatter = [&](auto WHOLE, uint32_t& pb) {                                  // (pb: an asm operand must not be a capture)
 #pragma unroll
-        for (uint32_t b8 = 0; b8 < 64; b8 += 8) {
-            if (b8 < nrows) {
+            for (uint32_t b8 = 0; b8 < 64; b8 += 8) {
+                if (b8 < nrows) {
 #pragma unroll
-                for (uint32_t u = 0; u < 8; ++u) {
-                    const uint2 mm = *reinterpret_cast<const uint2*>(&rowmeta[wave][b8 + u]);
-                    u32x2_t e; e.x = rowbr[wave][b8 + u]; e.y = val[b8 + u];
-                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mm.x & pm_lo));
-                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mm.y & pm_hi));
-                    asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, -1"
-                                 : "+v"(posb) : "v"(e), "s"(((uint64_t)hi << 32) | lo));
+                    for (uint32_t u = 0; u < 8; ++u) {
+                        uint2 mm = *reinterpret_cast<const uint2*>(&rowmeta[wave][b8 + u]);
+                        if constexpr (!decltype(WHOLE)::value) { mm.x &= pm_lo; mm.y &= pm_hi; }
+                        u32x2_t e; e.x = rowbr[wave][b8 + u]; e.y = val[b8 + u];
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.x);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.y);
+                        asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, -1"
+                                     : "+v"(pb) : "v"(e), "s"(((uint64_t)hi << 32) | lo));
+                    }
                 }
             }
-        }
+        };
+        if (pm == ~0ull) scatter(std::true_type{}, posb); else scatter(std::false_type{}, posb);
         __syncthreads();
 
         // copy out
