@@ -58,7 +58,19 @@ __global__ __launch_bounds__(256) void km_count_mask_kernel(const uint32_t* __re
     uint32_t q = 0;
     for (uint32_t g0 = 0; g0 < G; g0 += step, ++q) {
         const uint32_t g1 = min(G, g0 + step);
-        for (uint32_t g = g0; g < g1; ++g) {
+        uint32_t g = g0;
+        for (; g + 8 <= g1; g += 8) {                      // eight rows' loads in flight together
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = m[(size_t)(g + u) * W];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                uint32_t carry = v[u];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { const uint32_t t = plane[p] & carry; plane[p] ^= carry; carry = t; }
+            }
+        }
+        for (; g < g1; ++g) {
             uint32_t carry = m[(size_t)g * W];
 #pragma unroll
             for (int p = 0; p < 8; ++p) { const uint32_t t = plane[p] & carry; plane[p] ^= carry; carry = t; }
