@@ -7,7 +7,8 @@ taken as is (exact for 16-B/lane stores; the 8-B/lane pair stores of the scoring
 JSON).
 
 usage: pmc_traffic.py <fetch_csv> <write_csv> <workload> <out.json> <kernel-substring> [more substrings ...]
-(a substring may be several parts joined by '&': all must occur in the kernel name -- template instantiations)
+(a substring may be several parts joined by '&': all must occur in the kernel name -- template instantiations;
+'name=substring' stores the kernel under `name`).  <workload> must be the bench config's name (cfg2, cfg4 ...) for bench.py to use it.
 The first substring's kernel is also written at top level ("kernel", "hbm_bytes_per_launch"): bench.py reads that.
 """
 import csv
@@ -34,8 +35,10 @@ def main():
            "corrections": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads); WRITE_SIZE as is (8-B/lane stores uncalibrated); KiB -> bytes",
            "kernels": {}}
     for i, sub in enumerate(subs):
-        f, nf = per_launch(fetch_csv, "FETCH_SIZE", sub)
-        w, nw = per_launch(write_csv, "WRITE_SIZE", sub)
+        name, _, pat = sub.rpartition("=")                 # "name=pattern": the key under which bench.py looks the kernel up
+        sub, pat = (name or pat), pat
+        f, nf = per_launch(fetch_csv, "FETCH_SIZE", pat)
+        w, nw = per_launch(write_csv, "WRITE_SIZE", pat)
         if f is None or w is None:
             continue
         k = {"FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w, "launches": [nf, nw],

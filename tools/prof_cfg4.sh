@@ -12,4 +12,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -- python
 cp $(find $OUT/${TAG}_ks -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
 rm -rf $OUT/${TAG}_ks
 head -14 $OUT/${TAG}_kernel_stats.csv
-bash $ROOT/tools/prof_traffic.sh ${TAG} "cfg4 (AA k=6, 250 groups x 2 x 3000)" "km_write_c_kernel score_xp_kernel&true> score_xp_kernel&false> reduce_ranges_kernel km_count score_overflow_xp" --config cfg4
+bash $ROOT/tools/prof_traffic.sh ${TAG} cfg4 "score_xp_kernel<WRITE>=score_xp_kernel&true> score_xp_kernel<COUNT>=score_xp_kernel&false> reduce_ranges_kernel km_write_c_kernel km_count score_overflow_xp" --config cfg4
