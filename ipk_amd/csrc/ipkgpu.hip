@@ -1076,7 +1076,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / SNW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
     const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
     const uint64_t expected_chunks = (uint64_t)((double)windows * ppw_est / CH);
-    const uint64_t max_wg = std::max<uint64_t>(slots, expected_chunks / 2 / ((uint64_t)SNW * NBK * SUB));
+#ifndef IPK_WG_CHUNKS2
+#define IPK_WG_CHUNKS2 2      // a wavefront should fill at least IPK_WG_CHUNKS2 / 2 chunks per bucket (4: +3.5 % at a 125-group share of cfg2)
+#endif
+    const uint64_t max_wg = std::max<uint64_t>(slots, expected_chunks * 2 / IPK_WG_CHUNKS2 / ((uint64_t)SNW * NBK * SUB));
     // whole rounds of resident workgroups: a partial last round leaves CUs idle for a full workgroup's run time
 #ifndef IPK_ROUNDS
 #define IPK_ROUNDS 8
