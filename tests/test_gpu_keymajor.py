@@ -322,3 +322,28 @@ def test_native_exchange_single_rank_comm():
             p.free()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("n_groups,n_owners", [(300, 1), (250, 3), (70, 1), (5, 2)])
+def test_compressed_tables_keymajor_writers(engine, n_groups, n_owners):
+    """Key-major parts from the compressed table form (variant 4): up to 256 groups per batch take the row-wise writer
+    (four wavefronts, a quarter of the rows each, per-quarter counts from the counting kernel), more take the tile
+    version; one and several owners.  Every owner's shard against the oracle database."""
+    sigma, k, sites = 4, 6, 14
+    mats = synth_matrices(n_groups, sites, sigma, 0.3, 77 + n_groups)
+    groups = np.arange(n_groups, dtype=np.uint32) * 2 + 1
+    eps = co.log_threshold(1.0, sigma, k) - 0.3
+    full, emitted = oracle_db(mats, groups, k, eps)
+    engine.set_option("variant", 4)
+    try:
+        parts = engine.score_groups_keymajor(mats, groups, k, eps, n_owners=n_owners)
+    finally:
+        engine.set_option("variant", 0)
+    assert parts.emitted == emitted
+    for o in range(n_owners):
+        a, b = int(parts.owner_offsets[o]), int(parts.owner_offsets[o + 1])
+        db = engine.merge_parts(sigma, k, o, n_owners, parts.counts_tensor()[o:o + 1].contiguous(),
+                                parts.entries_tensor()[a:b].contiguous(), np.zeros(1, np.uint64))
+        check_shard(db, full, sigma, k, o, n_owners)
+        db.free()
+    parts.free()
