@@ -47,6 +47,29 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 // llvm.amdgcn.ballot on the i1 itself: HIP's __ballot() goes through an int and costs two extra VALU instructions
 // (v_cndmask + v_cmp) wherever the predicate is a combination of compares
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// A wave-uniform value that the compiler holds in a VGPR (the result of float VALU arithmetic on uniform inputs), moved
+// to an SGPR.  __builtin_amdgcn_readfirstlane is folded away when its argument is known to be uniform, which leaves loop
+// counters derived from it in VGPRs (exec-masked loops, quarter-rate v_mul_lo_u32); the asm form is opaque.
+__device__ __forceinline__ uint32_t to_sgpr(uint32_t x)
+{
+    uint32_t r;
+    asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(x));
+    return r;
+}
+
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+// One 8-byte record per lane of `mask` to uniform_base + byte_off (+ IMM bytes): the store form with a scalar base and a 32-bit
+// lane offset, the lanes selected by writing exec directly -- from code that runs with ALL lanes enabled (uniform control flow
+// in full wavefronts).  Two scalar instructions around the store instead of compare / and-saveexec / branch / restore.
+template <int IMM = 0>
+__device__ __forceinline__ void store8_lanes(const void* uniform_base, uint32_t byte_off, uint32_t x, uint32_t y, uint64_t mask)
+{
+    u32x2_t data; data.x = x; data.y = y;
+    asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2 offset:%4\n\ts_mov_b64 exec, -1"
+                 : : "v"(byte_off), "v"(data), "s"(uniform_base), "s"(mask), "n"(IMM) : "memory");
+}
+
 __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

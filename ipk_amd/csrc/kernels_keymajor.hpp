@@ -216,8 +216,6 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
     }
 }
 
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-
 // km_write_kernel reading the compressed form: the generic version (any number of groups; km_write_c_kernel below is the fast
 // one for up to 256 groups per batch).  Workgroup w takes key block (w % 8) * ceil(blocks / 8) + w / 8:
 // workgroups are dealt round-robin to the 8 XCDs, so each XCD walks one contiguous range of key blocks and the mask /

@@ -140,16 +140,6 @@ __device__ __forceinline__ void quad_step(const float* cols, uint32_t base, bool
     }
 }
 
-// A wave-uniform value that the compiler holds in a VGPR (the result of float VALU arithmetic on uniform inputs), moved
-// to an SGPR.  __builtin_amdgcn_readfirstlane is folded away when its argument is known to be uniform, which leaves loop
-// counters derived from it in VGPRs (exec-masked loops, quarter-rate v_mul_lo_u32); the asm form is opaque.
-__device__ __forceinline__ uint32_t to_sgpr(uint32_t x)
-{
-    uint32_t r;
-    asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(x));
-    return r;
-}
-
 // A pool store: wave-uniform base (SGPR pair) + 32-bit byte offset, i.e. the `global_store v_off, v_data, s[base]` form -- one
 // VALU instruction of address arithmetic per store instead of four for a 64-bit lane address.  The offsets are relative to the
 // wave's base chunk (RowAppender::rebase keeps every open chunk within 4 GiB of it).  (A structured-buffer form -- buffer_store

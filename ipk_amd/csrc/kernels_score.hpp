@@ -885,6 +885,7 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
     Cursor* cur = reinterpret_cast<Cursor*>(scratch_all + (size_t)NW * WS);     // workgroup-shared, one per bucket
 
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane8 = lane * 8u;
     const uint32_t g = blockIdx.x / p.S, seg = blockIdx.x - g * p.S;
     const uint32_t m0 = p.gm_off[g], nm = p.gm_off[g + 1] - m0;
     const uint32_t total_tiles = nm * p.tiles_per_mat;
@@ -1001,22 +1002,50 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
                     emitted += cnt;
                     if (cnt) atomicAdd(&cur[bk], cnt);
                 } else {
-                    unsigned long long pos = 0;            // the unit's range of the bucket starts at its scan offset
-                    if (cnt) pos = xp.off[ub + (size_t)bk * xp.stride] + atomicAdd(&cur[bk], cnt);
-                    const uint32_t rows = min(64u, nL - ib);
+                    // the unit's range of the bucket starts at its scan offset; every row's run as a byte address
+                    unsigned long long run = 0;
+                    if (cnt) run = reinterpret_cast<unsigned long long>(p.pool + (xp.off[ub + (size_t)bk * xp.stride] + atomicAdd(&cur[bk], cnt)));
+                    const uint32_t axm = a.x * mulR;
+                    const uint32_t rows = to_sgpr(min(64u, nL - ib));
+                    // One row at a time, its values broadcast with v_readlane; the row's passing prefix leaves through the
+                    // scalar-base store form with exec written directly (the loop is ~30 instructions per row otherwise, most of
+                    // them scalar address arithmetic and exec bookkeeping -- and this loop is half of the kernel's instructions)
                     for (uint32_t r = 0; r < rows; ++r) {
                         const uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)r);
-                        if (cr == 0) continue;
-                        const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos, (int)r);
-                        const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos >> 32), (int)r);
-                        uint2* dst = p.pool + (((unsigned long long)phi << 32) | plo);
-                        const uint32_t ax = (uint32_t)__builtin_amdgcn_readlane((int)a.x, (int)r) * mulR;
+                        const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)run, (int)r);
+                        const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(run >> 32), (int)r);
+                        const uint2* dst = reinterpret_cast<const uint2*>(((unsigned long long)rhi << 32) | rlo);
+                        const uint32_t ax = (uint32_t)__builtin_amdgcn_readlane((int)axm, (int)r);
                         const float ayr = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)a.y, (int)r));
-#pragma unroll
-                        for (int ch = 0; ch < RC; ++ch) {
-                            if ((uint32_t)ch * 64 >= cr) break;
-                            const uint32_t j = (uint32_t)ch * 64 + lane;
-                            if (j < cr) dst[j] = make_uint2(ax + rx[ch], __float_as_uint(ayr + ry[ch]));   // :90, the row's passing prefix
+                        auto chunk = [&](auto CH) {
+                            constexpr int ch = decltype(CH)::value;
+                            if constexpr (ch < RC) {
+                                const uint32_t left = cr - (uint32_t)ch * 64u;                       // (> 0 here)
+                                const uint64_t mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+                                store8_lanes<ch * 512>(dst, lane8, ax + rx[ch], __float_as_uint(ayr + ry[ch]), mask);   // :90, the row's passing prefix
+                            }
+                        };
+                        if (cr < 64) {                                  // the common case: one store, its lanes = the low cr bits
+                            unsigned long long mask;                    // (cr == 0: no lanes, the store is a no-op)
+                            asm("s_bfm_b64 %0, %1, 0" : "=s"(mask) : "s"(cr));
+                            store8_lanes<0>(dst, lane8, ax + rx[0], __float_as_uint(ayr + ry[0]), mask);
+                            continue;
+                        }
+                        chunk(std::integral_constant<int, 0>{});
+                        if (cr > 64) {
+                            chunk(std::integral_constant<int, 1>{});
+                            if (cr > 128) {
+                                chunk(std::integral_constant<int, 2>{});
+                                if (cr > 192) {
+                                    chunk(std::integral_constant<int, 3>{});
+                                    if (cr > 256) {
+                                        chunk(std::integral_constant<int, 4>{});
+                                        if (cr > 320) chunk(std::integral_constant<int, 5>{});
+                                        if (cr > 384) chunk(std::integral_constant<int, 6>{});
+                                        if (cr > 448) chunk(std::integral_constant<int, 7>{});
+                                    }
+                                }
+                            }
                         }
                     }
                 }
