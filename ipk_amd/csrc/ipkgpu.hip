@@ -1076,6 +1076,9 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / SNW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
     const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
     const uint64_t expected_chunks = (uint64_t)((double)windows * ppw_est / CH);
+#ifndef IPK_OVF_POOL_RATIO
+#define IPK_OVF_POOL_RATIO 500
+#endif
 #ifndef IPK_WG_CHUNKS2
 #define IPK_WG_CHUNKS2 2      // a wavefront should fill at least IPK_WG_CHUNKS2 / 2 chunks per bucket (4: +3.5 % at a 125-group share of cfg2)
 #endif
@@ -1148,7 +1151,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // a handful of big-list windows (< 0.2 % of the batch) are cheaper through the atomic kernel after pass 2 than
         // through sort + pool kernel; flat posteriors put a large share of the pairs there and need the pool
-        const bool ovf_in_pool = (uint64_t)n_ovf * 500 >= windows && gb < (1u << 22) && n_mats < (1u << 21) && pl.nwin < (1u << 21);
+        const bool ovf_in_pool = (uint64_t)n_ovf * IPK_OVF_POOL_RATIO >= windows && gb < (1u << 22) && n_mats < (1u << 21) && pl.nwin < (1u << 21);
         if (ovf_in_pool) {
             RC_TRY(ensure(ctx, ctx->tmp_a, (size_t)n_ovf * 8));
             RC_TRY(ensure(ctx, ctx->tmp_b, (size_t)n_ovf * 8));
