@@ -75,7 +75,7 @@ struct ipkgpu_ctx {
     uint64_t mask_words = 0;     // 2 * ceil(table_size / 64): rows padded to whole 64-slot blocks
     // compressed table form (exact-partition variant on sparse key spaces; comp_table.hpp): no dense ctx->table
     bool table_compressed = false;
-    DevBuf rank, vaddr, ucnt, qpack;
+    DevBuf rank, vaddr, ucnt, qpack, xstart;
     uint32_t comp_nb = 0, comp_stride = 0, comp_tbl = 0;
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
     double acc_main_ms = 0, acc_reduce_ms = 0;   // dominant scoring kernel / LDS reduce pass of the current call
@@ -291,7 +291,7 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
                       &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
                       &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->mask,
-                      &ctx->rank, &ctx->vaddr, &ctx->ucnt, &ctx->qpack, &ctx->ptrs};
+                      &ctx->rank, &ctx->vaddr, &ctx->ucnt, &ctx->qpack, &ctx->xstart, &ctx->ptrs};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
     ipkgpu_comm_release(ctx);
@@ -896,6 +896,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     xp.off = ctx->gboff.as<uint64_t>();
     xp.stride = stride;
     xp.ovcur = ctx->gbcur.as<uint32_t>();
+    xp.start = nullptr;
 
     Stopwatch sw(ctx->stream);
     const int ev_a = sw.mark();
@@ -914,6 +915,16 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
                         (unsigned long long)total);
     }
     RC_TRY(ensure(ctx, ctx->pool, std::max<uint64_t>(total, 1) * 8 + 256));     // (+256: km_write_c_kernel reads up to 32 values from a row's start)
+    {
+        // the write pass' cursors: every workgroup's NB starting offsets side by side, relative to its group's first pair
+        const uint64_t n_start = (uint64_t)gb * S * XNB;
+        RC_TRY(ensure(ctx, ctx->xstart, n_start * 4));
+        hipLaunchKernelGGL(xp_unit_starts_kernel, dim3((uint32_t)((n_start + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->gboff.as<uint64_t>(), XNB, S, stride, n_start, ctx->xstart.as<uint32_t>(),
+                           reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 56));
+        HIP_TRY(ctx, hipGetLastError());
+        xp.start = ctx->xstart.as<uint32_t>();
+    }
     sp.pool = ctx->pool.as<uint2>();
     const int ev_c = sw.mark();
     RC_TRY(dispatch_xp(ctx, pl.sigma, pl.k, xp, gb * S, true));
@@ -930,7 +941,10 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     RC_TRY(dispatch_xp_reduce(ctx, pl.sigma, pl.k, (uint32_t)n_gb, stride, pl.table_size, ctx->gboff.as<uint64_t>(),
                               compress ? nullptr : ctx->table.as<uint32_t>(), compress));
     const int ev_e = sw.mark();
+    uint32_t too_big = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&too_big, reinterpret_cast<char*>(ctx->small) + 56, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (too_big) return fail(ctx, IPKGPU_ERR_INVALID, "a branch group scores 2^32 phylo-k-mers or more in one batch (exact-partition variant: 32-bit offsets inside a group)");
     ctx->mask_valid = true;
     ctx->table_compressed = compress;
     ctx->comp_nb = XNB; ctx->comp_stride = stride; ctx->comp_tbl = xp_bucket_slots(pl.sigma, pl.k);

@@ -864,7 +864,26 @@ struct XpParams {
     const uint64_t* off;           // exclusive scan of cnt                        (write pass input)
     uint32_t stride;               // S + 1: segment S of every (group, bucket) belongs to the big-list windows
     uint32_t* ovcur;               // [group * NB + bucket] pairs the big-list write pass has placed so far
+    const uint32_t* start;         // [(group * S + segment) * NB + bucket] where the unit's range of the bucket starts, relative to
+                                   // off[group * NB * stride] (write pass: a workgroup's NB cursors as one contiguous load)
 };
+
+// start[(g * S + seg) * NB + b] = off[(g * NB + b) * stride + seg] - off[g * NB * stride]: the scan's offsets of one workgroup's
+// buckets are `stride` elements apart (a (group, bucket) range is contiguous over the segments); the write pass wants them side by
+// side -- one global load per row of L from that strided array was 13 GB of line fetches and a dependent load per row block.
+__global__ __launch_bounds__(256) void xp_unit_starts_kernel(const uint64_t* __restrict__ off, uint32_t NB, uint32_t S, uint32_t stride,
+                                                             uint64_t n, uint32_t* __restrict__ start, uint32_t* __restrict__ too_big)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;       // = (g * S + seg) * NB + b
+    if (i >= n) return;
+    const uint32_t b = (uint32_t)(i % NB);
+    const uint64_t u = i / NB;
+    const uint32_t seg = (uint32_t)(u % S);
+    const uint64_t g = u / S;
+    const uint64_t rel = off[(g * NB + b) * stride + seg] - off[g * NB * stride];
+    if (rel >> 32) atomicOr(too_big, 1u);                              // a group with 2^32 pairs or more (the host fails the call)
+    start[i] = (uint32_t)rel;
+}
 
 template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL, bool WRITE>
 __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
@@ -892,7 +911,14 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
     const uint32_t t_lo = (uint32_t)(((uint64_t)total_tiles * seg) / p.S);
     const uint32_t t_hi = (uint32_t)(((uint64_t)total_tiles * (seg + 1)) / p.S);
     const size_t ub = (size_t)g * NB * xp.stride + seg;     // this unit's slot of bucket b: ub + b * stride
-    for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) cur[b] = 0;    // (the first tile's barriers order this before any use)
+    // count pass: pairs of the bucket so far; write pass: where the bucket's next run goes, relative to the group's first pair
+    if constexpr (WRITE) {
+        const uint32_t* st = xp.start + (size_t)blockIdx.x * NB;       // (blockIdx.x = g * S + seg)
+        for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) cur[b] = st[b];
+    } else {
+        for (uint32_t b = threadIdx.x; b < NB; b += NW * 64) cur[b] = 0;
+    }                                                                   // (the first tile's barriers order this before any use)
+    const uint2* group_pool = WRITE ? p.pool + xp.off[(size_t)g * NB * xp.stride] : nullptr;
 
     uint2* scratch = scratch_all + (size_t)wave * WS;
     unsigned long long emitted = 0;                         // per lane
@@ -1002,9 +1028,9 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
                     emitted += cnt;
                     if (cnt) atomicAdd(&cur[bk], cnt);
                 } else {
-                    // the unit's range of the bucket starts at its scan offset; every row's run as a byte address
+                    // the bucket's cursor started at the unit's scan offset; every row's run as a byte address
                     unsigned long long run = 0;
-                    if (cnt) run = reinterpret_cast<unsigned long long>(p.pool + (xp.off[ub + (size_t)bk * xp.stride] + atomicAdd(&cur[bk], cnt)));
+                    if (cnt) run = reinterpret_cast<unsigned long long>(group_pool + atomicAdd(&cur[bk], cnt));
                     const uint32_t axm = a.x * mulR;
                     const uint32_t rows = to_sgpr(min(64u, nL - ib));
                     // One row at a time, its values broadcast with v_readlane; the row's passing prefix leaves through the
