@@ -333,6 +333,25 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
     const uint64_t x0 = kb * 64;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
 
+    // this wavefront's rows [r0, r0 + nrows), nrows <= 64.  Their occupancy bits, value addresses and branch ids come in with
+    // ONE coalesced-as-can-be load each (lane = row) and are staged in LDS, from where every row's are read back as broadcasts:
+    // the per-row values are wave-uniform without a chain of scalar-load round trips (a first version that fetched them with
+    // s_load, eight rows at a time, spent its time waiting for those).  The loads are issued first thing, together with the keys'
+    // counts and cursors below: one round trip for all of them.
+    const uint32_t rq = (G + 3) / 4, r0 = min(G, wave * rq), nrows = min(G, r0 + rq) - r0;
+    uint64_t row_m = 0, row_va = reinterpret_cast<uint64_t>(ct.pool);                    // (rows past the end: no bits, any readable address)
+    uint32_t row_br = 0;
+    {
+        const uint32_t row_bytes = (uint32_t)(ct.mask_words / 2) * 8u;                   // a row of bits / of addresses
+        const bool live = lane < nrows;
+        const size_t ro = (size_t)(r0 + (live ? lane : 0u)) * row_bytes;
+        if (live) {
+            row_m = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(reinterpret_cast<const uint64_t*>(ct.mask) + kb) + ro);
+            row_va = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(ct.vaddr + kb) + ro);
+            row_br = branch_of_group[r0 + lane];
+        }
+    }
+
     // this lane's key: where it lives, and how many rows of the quarters before this wavefront's hold it
     const uint64_t x = x0 + lane;
     const size_t cidx = x < T ? (ONE_OWNER ? (size_t)x : (size_t)((x % P) * slots + x / P)) : 0;
@@ -351,25 +370,8 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
         if (threadIdx.x == 0) kpre[0] = 0;
     }
 
-    // this wavefront's rows [r0, r0 + nrows), nrows <= 64.  Their occupancy bits, value addresses and branch ids come in with
-    // ONE coalesced-as-can-be load each (lane = row) and are staged in LDS, from where every row's are read back as broadcasts:
-    // the per-row values are wave-uniform without a chain of scalar-load round trips (a first version that fetched them with
-    // s_load, eight rows at a time, spent its time waiting for those).
-    const uint32_t rq = (G + 3) / 4, r0 = min(G, wave * rq), nrows = min(G, r0 + rq) - r0;
-    {
-        const uint32_t row_bytes = (uint32_t)(ct.mask_words / 2) * 8u;                   // a row of bits / of addresses
-        const bool live = lane < nrows;
-        const size_t ro = (size_t)(r0 + (live ? lane : 0u)) * row_bytes;
-        uint64_t m = 0, va = reinterpret_cast<uint64_t>(ct.pool);                        // (rows past the end: no bits, any readable address)
-        uint32_t br = 0;
-        if (live) {
-            m = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(reinterpret_cast<const uint64_t*>(ct.mask) + kb) + ro);
-            va = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(ct.vaddr + kb) + ro);
-            br = branch_of_group[r0 + lane];
-        }
-        rowmeta[wave][lane] = make_uint4((uint32_t)m, (uint32_t)(m >> 32), (uint32_t)va, (uint32_t)(va >> 32));
-        rowbr[wave][lane] = br;
-    }
+    rowmeta[wave][lane] = make_uint4((uint32_t)row_m, (uint32_t)(row_m >> 32), (uint32_t)row_va, (uint32_t)(row_va >> 32));
+    rowbr[wave][lane] = row_br;
     // the value loads of all rows, none waited for here.  Every lane loads: a lane without the key reads the value of the next
     // key that has one (or, past the row's end, whatever follows it in the pool, which is allocated 256 B longer for this) and
     // does not store it.
