@@ -838,20 +838,21 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
 // equal to the count pass' number) and leave as one dense run, the lanes over the prefix.  Same sets, same float operation per pair as for_each_pair/join
 // (pk_compute.cpp:90-91).
 // =================================================================================================
-// rank[c] += #{i < n : key(R[i]) > kj[c]} for the lane's NCH keys; key = (score code << 32) | ~position.
-// Four LDS reads in flight per trip; NCH is a compile-time count so the body is branch-free.
+// rank[c] += #{i < n : key(R[i]) > kj[c]} for the lane's NCH keys; key = (score code << 32) | ~position.  The lanes already hold
+// every key (entry j = ch * 64 + lane in kj[ch]): entry i's key is broadcast from there with two v_readlane into scalar registers
+// and compared with the lane's keys as a scalar operand -- no LDS read, no re-encoding of a wave-uniform value in every lane, no
+// padding entries.  NCH is a compile-time count so the body is branch-free.
 template <int NCH, int RC>
-__device__ __forceinline__ void xp_rank_by_counting(const uint2* R, uint32_t n, const unsigned long long (&kj)[RC], uint32_t (&rank)[RC])
+__device__ __forceinline__ void xp_rank_by_counting(uint32_t n, const unsigned long long (&kj)[RC], uint32_t (&rank)[RC])
 {
-    for (uint32_t i = 0; i < n; i += 4) {
-        uint32_t e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = R[min(i + (uint32_t)u, n - 1)].y;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            // entries past the end repeat the last one with a position that loses every comparison it should not win
-            const bool live = i + (uint32_t)u < n;
-            const unsigned long long ki = live ? (((unsigned long long)enc_score_bits(e[u]) << 32) | (unsigned long long)(0xFFFFFFFFu - (i + (uint32_t)u))) : 0ull;
+    for (int ci = 0; ci < NCH; ++ci) {
+        const uint32_t lo = (uint32_t)kj[ci], hi = (uint32_t)(kj[ci] >> 32);
+        const uint32_t m = min(64u, n - min(n, (uint32_t)ci * 64u));           // entries of chunk ci
+#pragma unroll 4
+        for (uint32_t l = 0; l < m; ++l) {
+            const unsigned long long ki = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, (int)l) << 32) |
+                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lo, (int)l);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) rank[c] += (ki > kj[c]) ? 1u : 0u;
         }
@@ -980,11 +981,11 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
                     }
                 }
                 switch ((nR + 63) >> 6) {
-                    case 1: xp_rank_by_counting<1, RC>(R, nR, kj, rank); break;
-                    case 2: if constexpr (RC >= 2) xp_rank_by_counting<2, RC>(R, nR, kj, rank); break;
-                    case 3: if constexpr (RC >= 3) xp_rank_by_counting<3, RC>(R, nR, kj, rank); break;
-                    case 4: if constexpr (RC >= 4) xp_rank_by_counting<4, RC>(R, nR, kj, rank); break;
-                    default: xp_rank_by_counting<RC, RC>(R, nR, kj, rank); break;
+                    case 1: xp_rank_by_counting<1, RC>(nR, kj, rank); break;
+                    case 2: if constexpr (RC >= 2) xp_rank_by_counting<2, RC>(nR, kj, rank); break;
+                    case 3: if constexpr (RC >= 3) xp_rank_by_counting<3, RC>(nR, kj, rank); break;
+                    case 4: if constexpr (RC >= 4) xp_rank_by_counting<4, RC>(nR, kj, rank); break;
+                    default: xp_rank_by_counting<RC, RC>(nR, kj, rank); break;
                 }
                 wave_lds_sync();                           // every lane has read the unsorted list
 #pragma unroll
