@@ -21,6 +21,12 @@
  * pointer (logp_dev, counts_dev, entries_dev ...) must be complete before the call: synchronise the
  * stream that produced them (hipStreamSynchronize / hipEventSynchronize) first.  Every call returns
  * after its device work has finished, so results may be read from any stream afterwards.
+ *
+ * Not supported (IPKGPU_ERR_INVALID, never a silent fallback): k-mer codes beyond 32 bits -- DNA k > 12,
+ * amino acids k > 6 (the reference's command line advertises k <= 31, ipk.py:116; its key type here is
+ * u32) -- and the reference's on-disk mode (db_builder.cpp:673-681, branch_group.cpp:109-185: per-group
+ * files merged later): groups are batched by device memory instead ("workspace_bytes") and the k-mer-keyed
+ * merge of batches / ranks runs on the device (ipkgpu_merge_parts*).
  */
 #ifndef IPKGPU_H
 #define IPKGPU_H
