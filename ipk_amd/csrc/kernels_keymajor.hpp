@@ -183,37 +183,56 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
                                                        uint2* __restrict__ entries)
 {
     __shared__ uint32_t tile[64][65];
-    __shared__ uint64_t run[64];
     const uint64_t x0 = (uint64_t)blockIdx.x * 64;
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    if (threadIdx.x < 64) {
-        const uint64_t x = x0 + threadIdx.x;
-        run[threadIdx.x] = (x < T) ? cursor[(x % P) * slots + x / P] : 0;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    // this wavefront's 16 keys x0 + wave + 4 t: their output positions as scalar pointers, advanced by the popcount of each
+    // step's ballot (no LDS round trip and no 64-bit lane arithmetic per store)
+    size_t cidx = 0;
+    uint64_t cur = 0;
+    const bool mine = lane < 16 && x0 + wave + 4u * lane < T;
+    if (mine) {
+        const uint64_t x = x0 + wave + 4u * lane;
+        cidx = (size_t)((x % P) * slots + x / P);
+        cur = cursor[cidx];
     }
+    uint2* dst[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur, t);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), t);
+        dst[t] = entries + (((uint64_t)hi << 32) | lo);
+    }
+    const uint32_t xl = threadIdx.x & 63u;
+    const bool xok = x0 + xl < T;
     for (uint32_t g0 = 0; g0 < G; g0 += 64) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < 4096; i += 256) {
-            const uint32_t gl = i >> 6, xl = i & 63u;
-            uint32_t v = 0;
-            if (g0 + gl < G && x0 + xl < T) v = table[(size_t)(g0 + gl) * T + x0 + xl];
-            tile[gl][xl] = v;
+        // the tile's 16 rows per wavefront: all loads issued before any is used (one at a time, each waited for, this loop was
+        // sixteen memory round trips per tile)
+        uint32_t v[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) {
+            const uint32_t gl = wave + 4u * u;
+            v[u] = 0;
+            if (g0 + gl < G && xok) v[u] = table[(size_t)(g0 + gl) * T + x0 + xl];
         }
-        __syncthreads();
         const uint32_t br = (g0 + lane < G) ? branch_of_group[g0 + lane] : 0u;
-        for (uint32_t xl = wave; xl < 64; xl += 4) {
-            const uint32_t v = tile[lane][xl];
-            const uint64_t m = __ballot(v != 0u);
-            if (m == 0) continue;
-            const uint64_t base = run[xl];
-            if (v != 0u) entries[base + mbcnt(m)] = make_uint2(br, dec_score_bits(v));
-            if (lane == 0) run[xl] = base + (uint64_t)__popcll(m);
+        __syncthreads();                                     // the previous tile is consumed
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) tile[wave + 4u * u][xl] = v[u];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t w = tile[lane][wave + 4u * (uint32_t)t];
+            const uint64_t cm = ballot64(w != 0u);
+            store8_lanes(dst[t], mbcnt(cm) << 3, br, dec_score_bits(w), cm);
+            dst[t] += __popcll(cm);
         }
     }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const uint64_t x = x0 + threadIdx.x;
-        if (x < T) cursor[(x % P) * slots + x / P] = run[threadIdx.x];
-    }
+    // the advanced cursors (batches of groups append in order)
+    uint64_t fin = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        if (lane == (uint32_t)t) fin = (uint64_t)(dst[t] - entries);
+    if (mine) cursor[cidx] = fin;
 }
 
 // km_write_kernel reading the compressed form: the generic version (any number of groups; km_write_c_kernel below is the fast
