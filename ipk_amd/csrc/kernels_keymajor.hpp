@@ -111,10 +111,12 @@ __global__ __launch_bounds__(256) void km_count_mask_key_kernel(const uint32_t* 
     for (uint32_t g0 = 0; g0 < G; g0 += step, ++q) {
         const uint32_t g1 = min(G, g0 + step);
         uint32_t c = 0, g = g0;
-        for (; g + 4 <= g1; g += 4) {
-            const uint32_t v0 = m[(size_t)(g + 0) * W], v1 = m[(size_t)(g + 1) * W];
-            const uint32_t v2 = m[(size_t)(g + 2) * W], v3 = m[(size_t)(g + 3) * W];
-            c += ((v0 >> sh) & 1u) + ((v1 >> sh) & 1u) + ((v2 >> sh) & 1u) + ((v3 >> sh) & 1u);
+        for (; g + 16 <= g1; g += 16) {                     // sixteen rows' loads in flight together
+            uint32_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = m[(size_t)(g + u) * W];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c += (v[u] >> sh) & 1u;
         }
         for (; g < g1; ++g) c += (m[(size_t)g * W] >> sh) & 1u;
         total += c;

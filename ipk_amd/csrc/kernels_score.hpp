@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict
                                                          float* __restrict__ best)
 {
     constexpr int CH = 4096;
-    __shared__ __align__(16) float cm[CH];
+    __shared__ float cm[CH];
     __shared__ float carry;
     const uint32_t mat = blockIdx.x;
     const float* m = logp + (size_t)mat * sites * SIGMA;
@@ -23,68 +23,31 @@ __global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict
     if (threadIdx.x == 0) { carry = 0.0f; b[0] = 0.0f; }
     for (uint32_t c0 = 0; c0 < sites; c0 += CH) {
         const uint32_t n = min((uint32_t)CH, sites - c0);
-        // column maxima: a thread's CH / 256 columns, their loads in flight together
-        constexpr int PER = CH / 256;
-        constexpr int UB = SIGMA == 4 ? PER : 4;               // columns per thread whose loads are issued before any is used
-        for (int u0 = 0; u0 < PER; u0 += UB) {
-            float4 v[UB][SIGMA / 4];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const uint32_t j = threadIdx.x + (uint32_t)(u0 + u) * 256u;
-                if (j < n) {
-                    const float4* col = reinterpret_cast<const float4*>(m + (size_t)(c0 + j) * SIGMA);
-#pragma unroll
-                    for (int q = 0; q < SIGMA / 4; ++q) v[u][q] = col[q];
-                }
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+            const float4* col = reinterpret_cast<const float4*>(m + (size_t)(c0 + j) * SIGMA);
+            float largest;
+            {
+                const float4 v = col[0];
+                largest = v.x;                                  // std::max_element: first largest
+                if (largest < v.y) largest = v.y;
+                if (largest < v.z) largest = v.z;
+                if (largest < v.w) largest = v.w;
             }
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const uint32_t j = threadIdx.x + (uint32_t)(u0 + u) * 256u;
-                if (j < n) {
-                    float largest = v[u][0].x;                  // std::max_element: first largest
-                    if (largest < v[u][0].y) largest = v[u][0].y;
-                    if (largest < v[u][0].z) largest = v[u][0].z;
-                    if (largest < v[u][0].w) largest = v[u][0].w;
-#pragma unroll
-                    for (int q = 1; q < SIGMA / 4; ++q) {
-                        if (largest < v[u][q].x) largest = v[u][q].x;
-                        if (largest < v[u][q].y) largest = v[u][q].y;
-                        if (largest < v[u][q].z) largest = v[u][q].z;
-                        if (largest < v[u][q].w) largest = v[u][q].w;
-                    }
-                    cm[j] = largest;
-                }
+            for (int q = 1; q < SIGMA / 4; ++q) {
+                const float4 v = col[q];
+                if (largest < v.x) largest = v.x;
+                if (largest < v.y) largest = v.y;
+                if (largest < v.z) largest = v.z;
+                if (largest < v.w) largest = v.w;
             }
+            cm[j] = largest;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            // the running sum, strictly in site order.  32 values per trip through 16-byte LDS accesses, the next trip's
-            // reads issued before this trip's chain of dependent adds -- the chain itself is the floor
             float acc = carry;
-            const uint32_t n32 = n & ~31u;
-            float4* c4 = reinterpret_cast<float4*>(cm);
-            float4 cur[8], nxt[8];
-            if (n32) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) cur[q] = c4[q];
-            }
-            for (uint32_t j = 0; j < n32; j += 32) {
-                if (j + 32 < n32) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) nxt[q] = c4[(j + 32) / 4 + q];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    acc += cur[q].x; cur[q].x = acc;
-                    acc += cur[q].y; cur[q].y = acc;
-                    acc += cur[q].z; cur[q].z = acc;
-                    acc += cur[q].w; cur[q].w = acc;
-                    c4[j / 4 + q] = cur[q];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
-            }
-            for (uint32_t j = n32; j < n; ++j) { acc += cm[j]; cm[j] = acc; }
+#pragma unroll 8
+            for (uint32_t j = 0; j < n; ++j) { acc += cm[j]; cm[j] = acc; }
             carry = acc;
         }
         __syncthreads();
