@@ -328,9 +328,18 @@ constexpr int NW = 8;    // wavefronts per workgroup
 #ifndef IPK_AACAP
 #define IPK_AACAP 512
 #endif
+#ifndef IPK_QCAP12
+#define IPK_QCAP12 320      // DNA k = 11, 12: 8 wavefronts per CU instead of 7 with 512 (cfg3 share: 21.1 against 21.8 ms; 256 / 160: the big-list windows cost more than the waves buy)
+#endif
+#ifndef IPK_QNW12
+#define IPK_QNW12 8
+#endif
+#ifndef IPK_QTW12
+#define IPK_QTW12 128
+#endif
 template <int SIGMA, int K> constexpr int fast_cap()
 {
-    if (SIGMA == 4) return K <= 10 ? IPK_QCAP : 512;
+    if (SIGMA == 4) return K <= 10 ? IPK_QCAP : IPK_QCAP12;
     return IPK_AACAP;
 }
 
@@ -479,8 +488,8 @@ template <int SIGMA, int K> constexpr bool quad_ok() { return QuadGeo<SIGMA, K>:
 #ifndef IPK_QTW
 #define IPK_QTW 40
 #endif
-template <int SIGMA, int K> constexpr int quad_nw() { return K <= 10 ? IPK_QNW : 7; }
-template <int SIGMA, int K> constexpr int quad_tw() { return K <= 10 ? IPK_QTW : 128; }
+template <int SIGMA, int K> constexpr int quad_nw() { return K <= 10 ? IPK_QNW : IPK_QNW12; }
+template <int SIGMA, int K> constexpr int quad_tw() { return K <= 10 ? IPK_QTW : IPK_QTW12; }
 template <int SIGMA, int K> size_t quad_lds()
 {
     if constexpr (!quad_ok<SIGMA, K>()) return 0;
