@@ -341,11 +341,11 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
         __syncthreads();
 
         const uint32_t npair = (nw + 1) / 2;
-        for (uint32_t pr = wave; pr < npair; pr += NW) {
+        const float* thw = thr + __umul24(wave * 2u + half, (uint32_t)Q::TH_F);     // this lane's window's thresholds: advanced, not recomputed
+        for (uint32_t pr = wave; pr < npair; pr += NW, thw += 2 * NW * Q::TH_F) {
             const uint32_t wq = pr * 2;
             const uint32_t wl = wq + half;                                       // this lane's window
             const bool wvalid = wl < nw;
-            const float* thw = thr + __umul24(wl, (uint32_t)Q::TH_F);
             uint32_t counts[3] = {0, 0, 0};                                      // per step: list length of this lane's slot
             wave_lds_sync();                                                     // the previous pair's lists are consumed
             auto run_step = [&](auto S) {

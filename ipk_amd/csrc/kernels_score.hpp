@@ -812,7 +812,6 @@ __device__ __forceinline__ void xp_rank_by_counting(uint32_t n, const unsigned l
     for (int ci = 0; ci < NCH; ++ci) {
         const uint32_t lo = (uint32_t)kj[ci], hi = (uint32_t)(kj[ci] >> 32);
         const uint32_t m = min(64u, n - min(n, (uint32_t)ci * 64u));           // entries of chunk ci
-#pragma unroll 4
         for (uint32_t l = 0; l < m; ++l) {
             const unsigned long long ki = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, (int)l) << 32) |
                                           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lo, (int)l);
