@@ -324,7 +324,7 @@ def test_native_exchange_single_rank_comm():
         eng.close()
 
 
-@pytest.mark.parametrize("n_groups,n_owners", [(300, 1), (250, 3), (70, 1), (5, 2)])
+@pytest.mark.parametrize("n_groups,n_owners", [(300, 1), (257, 1), (256, 1), (250, 3), (70, 1), (5, 2), (1, 1)])
 def test_compressed_tables_keymajor_writers(engine, n_groups, n_owners):
     """Key-major parts from the compressed table form (variant 4): up to 256 groups per batch take the row-wise writer
     (four wavefronts, a quarter of the rows each, per-quarter counts from the counting kernel), more take the tile
