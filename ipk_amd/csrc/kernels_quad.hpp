@@ -167,6 +167,22 @@ __device__ __forceinline__ void pool_store_lanes(uint2* wave_base, uint32_t byte
                  : : "v"(byte_off), "v"(data), "s"(wave_base), "s"(mask) : "memory");
 }
 
+// The store of a join step: of the lanes of `pass`, those whose slot v lies inside the open chunk (v < CH) store; the others
+// are returned (they wait for the bucket's next chunk).  exec = pass, then v_cmpx narrows it to the lanes inside -- the compare
+// writes exec itself, so the whole selection costs three scalar instructions.  From code that runs with ALL lanes enabled.
+__device__ __forceinline__ uint64_t pool_store_inside(uint2* wave_base, uint32_t byte_off, uint2 val, uint32_t v, uint64_t pass)
+{
+    const unsigned long long data = ((unsigned long long)val.y << 32) | val.x;
+    uint64_t outside;
+    asm volatile("s_mov_b64 exec, %5\n\t"
+                 "v_cmpx_gt_u32_e32 vcc, %6, %4\n\t"
+                 "global_store_dwordx2 %1, %2, %3\n\t"
+                 "s_andn2_b64 %0, %5, exec\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "=&s"(outside) : "v"(byte_off), "v"(data), "s"(wave_base), "v"(v), "s"(pass), "s"(CH) : "memory", "vcc");
+    return outside;
+}
+
 constexpr uint32_t QUAD_SPAN_CHUNKS = 1u << 21;   // chunks of CH * 8 = 2 KiB: 2^21 of them span 4 GiB
 constexpr uint32_t QUAD_SPAN_TEST = 8;            // debug_flags bit 3: rebase every 8 chunks (tests of the rebasing path)
 
@@ -481,11 +497,8 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                             const uint32_t where = (uint32_t)__builtin_amdgcn_ds_bpermute(head_addr, (int)(uint32_t)(got[u] >> 32));
                             v[u] = fill + rank[u];
                             val[u] = make_uint2(a[u].x + b.x, __float_as_uint(s[u]));
-                            const bool in = v[u] < CH;
-                            const uint64_t bin = ballot64(in);
-                            ovf[u] = m[u] & ~bin;
+                            ovf[u] = pool_store_inside(app.base, lshl3_add(v[u], where), val[u], v[u], m[u]);
                             anyo |= ovf[u];
-                            pool_store_lanes(app.base, lshl3_add(v[u], where), val[u], m[u] & bin);
                         }
                         while (anyo) {                                                // a bucket's chunk filled up: open a new one
                             uint32_t bb = 0;
