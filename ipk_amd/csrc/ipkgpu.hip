@@ -75,7 +75,7 @@ struct ipkgpu_ctx {
     uint64_t mask_words = 0;     // 2 * ceil(table_size / 64): rows padded to whole 64-slot blocks
     // compressed table form (exact-partition variant on sparse key spaces; comp_table.hpp): no dense ctx->table
     bool table_compressed = false;
-    DevBuf rank, vaddr, ucnt, qpack, xstart;
+    DevBuf rank, vaddr, ucnt, qpack, xstart, pcounts;
     uint32_t comp_nb = 0, comp_stride = 0, comp_tbl = 0;
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
     double acc_main_ms = 0, acc_reduce_ms = 0;   // dominant scoring kernel / LDS reduce pass of the current call
@@ -291,7 +291,7 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
                       &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
                       &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->mask,
-                      &ctx->rank, &ctx->vaddr, &ctx->ucnt, &ctx->qpack, &ctx->xstart, &ctx->ptrs};
+                      &ctx->rank, &ctx->vaddr, &ctx->ucnt, &ctx->qpack, &ctx->xstart, &ctx->pcounts, &ctx->ptrs};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
     ipkgpu_comm_release(ctx);
@@ -1726,11 +1726,12 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         Batch& b = batches.back();
         HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.counts, n_slots_all * 4));
         HIP_TRY(ctx, hipMemsetAsync(b.counts, 0, n_slots_all * 4, ctx->stream));
-        // compressed tables of up to 256 groups go through the fast key-major writer, which wants the rows counted per quarter
+        // compressed tables go through the fast key-major writer, up to 256 groups at a time: it wants those rows counted per quarter
+        const bool fast_c = ctx->table_compressed && 64ull * (ctx->mask_words / 2) * 8 < (1ull << 32);
         uint32_t* qpack = nullptr;
-        if (ctx->table_compressed && gb <= 256 && 64ull * (ctx->mask_words / 2) * 8 < (1ull << 32)) {
+        if (fast_c) {
             RC_TRY(ensure(ctx, ctx->qpack, n_slots_all * 4));
-            qpack = ctx->qpack.as<uint32_t>();
+            if (gb <= 256) qpack = ctx->qpack.as<uint32_t>();          // one pass: the total counts are the pass' counts
         }
         if (ctx->mask_valid && (T + 31) / 32 >= (uint64_t)ctx->num_cu * 1024)      // a thread per mask word fills the chip
             hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)(((T + 31) / 32 + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -1759,7 +1760,29 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
             if (qpack)
                 KM_LAUNCH(km_write_c_kernel, KMC_CAP, comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots, b.counts,
                           qpack, ctx->offsets.as<uint64_t>(), b.entries);
-            else
+            else if (fast_c) {
+                // more than 256 groups: passes of 256, each with its own counts; the cursors (the scan of the TOTAL counts) advance
+                // from pass to pass, so a key's entries stay in group order
+                RC_TRY(ensure(ctx, ctx->pcounts, n_slots_all * 4));
+                for (uint32_t p0 = 0; p0 < gb; p0 += 256) {
+                    const uint32_t pg = std::min<uint32_t>(256, gb - p0);
+                    const uint32_t* pmask = ctx->mask.as<uint32_t>() + (size_t)p0 * ctx->mask_words;
+                    if ((T + 31) / 32 >= (uint64_t)ctx->num_cu * 1024)
+                        hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)(((T + 31) / 32 + 255) / 256)), dim3(256), 0, ctx->stream,
+                                           pmask, ctx->mask_words, T, pg, P, slots, ctx->pcounts.as<uint32_t>(), ctx->qpack.as<uint32_t>());
+                    else
+                        hipLaunchKernelGGL(km_count_mask_key_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
+                                           pmask, ctx->mask_words, T, pg, P, slots, ctx->pcounts.as<uint32_t>(), ctx->qpack.as<uint32_t>());
+                    HIP_TRY(ctx, hipGetLastError());
+                    CompTable ctp = comp_table(ctx);
+                    ctp.mask = pmask;
+                    ctp.vaddr += (size_t)p0 * (ctx->mask_words / 2);
+                    ctp.rank += (size_t)p0 * (ctx->mask_words / 2);
+                    KM_LAUNCH(km_write_c_kernel, KMC_CAP, ctp, T, pg, ctx->branch.as<uint32_t>() + g0 + p0, P, slots, ctx->pcounts.as<uint32_t>(),
+                              ctx->qpack.as<uint32_t>(), ctx->offsets.as<uint64_t>(), b.entries);
+                    HIP_TRY(ctx, hipGetLastError());
+                }
+            } else
                 hipLaunchKernelGGL(km_write_c_generic_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
                                    comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
                                    ctx->offsets.as<uint64_t>(), b.entries);
