@@ -329,13 +329,14 @@ constexpr int NW = 8;    // wavefronts per workgroup
 #define IPK_AACAP 512
 #endif
 #ifndef IPK_QCAP12
-#define IPK_QCAP12 320      // DNA k = 11, 12: 8 wavefronts per CU instead of 7 with 512 (cfg3 share: 21.1 against 21.8 ms; 256 / 160: the big-list windows cost more than the waves buy)
+#define IPK_QCAP12 416      // DNA k = 11, 12: the largest half-list capacity that leaves three 3-wavefront workgroups per CU (512: two; cfg3 share 18.6 ms
+                            // against 19.1 at 320 -- fewer big-list windows -- and 21.8 with the round-1 shape of one 7-wavefront workgroup at 512)
 #endif
 #ifndef IPK_QNW12
-#define IPK_QNW12 8
+#define IPK_QNW12 3        // with 64-window tiles: three workgroups of three wavefronts per CU (cfg3 share: scoring 9.0 ms against 10.3 with one of eight)
 #endif
 #ifndef IPK_QTW12
-#define IPK_QTW12 128
+#define IPK_QTW12 64
 #endif
 template <int SIGMA, int K> constexpr int fast_cap()
 {
