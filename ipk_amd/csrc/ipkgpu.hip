@@ -524,7 +524,10 @@ int launch_quad_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
 #ifndef IPK_XPNW
 #define IPK_XPNW 11
 #endif
-constexpr int XP_TW = 128;
+#ifndef IPK_XPTW
+#define IPK_XPTW 128
+#endif
+constexpr int XP_TW = IPK_XPTW;
 template <int SIGMA, int K> constexpr int xp_nw() { return SIGMA == 20 ? IPK_XPNW : 11; }   // 11 waves: what fits 160 KB of LDS at AA k=6 (12 with 64-window tiles measured equal)
 template <int SIGMA, int K> constexpr uint32_t xp_tbl()
 {
