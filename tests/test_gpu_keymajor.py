@@ -324,11 +324,11 @@ def test_native_exchange_single_rank_comm():
         eng.close()
 
 
-@pytest.mark.parametrize("n_groups,n_owners", [(300, 1), (257, 1), (256, 1), (250, 3), (70, 1), (5, 2), (1, 1)])
+@pytest.mark.parametrize("n_groups,n_owners", [(300, 1), (600, 4), (257, 1), (256, 1), (250, 3), (70, 1), (5, 2), (1, 1)])
 def test_compressed_tables_keymajor_writers(engine, n_groups, n_owners):
     """Key-major parts from the compressed table form (variant 4): up to 256 groups per batch take the row-wise writer
-    (four wavefronts, a quarter of the rows each, per-quarter counts from the counting kernel), more take the tile
-    version; one and several owners.  Every owner's shard against the oracle database."""
+    (four wavefronts, a quarter of the rows each, per-quarter counts from the counting kernel), more take it in passes
+    of 256 with the cursors advancing; one and several owners.  Every owner's shard against the oracle database."""
     sigma, k, sites = 4, 6, 14
     mats = synth_matrices(n_groups, sites, sigma, 0.3, 77 + n_groups)
     groups = np.arange(n_groups, dtype=np.uint32) * 2 + 1
