@@ -76,6 +76,7 @@ struct ipkgpu_ctx {
     // compressed table form (exact-partition variant on sparse key spaces; comp_table.hpp): no dense ctx->table
     bool table_compressed = false;
     DevBuf rank, vaddr, ucnt, qpack, xstart, pcounts;
+    std::vector<uint32_t> h_branch;     // host copy of the last call's branch ids (source of an asynchronous upload)
     uint32_t comp_nb = 0, comp_stride = 0, comp_tbl = 0;
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
     double acc_main_ms = 0, acc_reduce_ms = 0;   // dominant scoring kernel / LDS reduce pass of the current call
@@ -1173,8 +1174,12 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         // windows whose half lists overflowed the fast path: big-list kernel.  With the queue sorted by group it
         // appends to the same pool (LDS max-reduce in pass 2); otherwise (field widths exceeded) it falls back to
         // global atomics on the finished tables after pass 2.
+        // (one host round trip for the queue length and the pool's state: they are read again below only if the big-list windows
+        //  go through the pool, which draws chunks too)
         uint32_t n_ovf = 0;
+        uint32_t h[2] = {0, 0};
         HIP_TRY(ctx, hipMemcpyAsync(&n_ovf, p.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h, d_pool_next, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // a handful of big-list windows (< 0.2 % of the batch) are cheaper through the atomic kernel after pass 2 than
         // through sort + pool kernel; flat posteriors put a large share of the pairs there and need the pool
@@ -1197,9 +1202,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
             if (use_quad) so.emitted = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->small) + 48);
             RC_TRY(dispatch_stream_overflow(ctx, pl.sigma, pl.k, so));
         }
-        uint32_t h[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpyAsync(h, d_pool_next, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ovf_in_pool) {
+            HIP_TRY(ctx, hipMemcpyAsync(h, d_pool_next, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
         if (h[1] != 0) {                    // pool exhausted: h[0] chunks were asked for
             if (cap >= max_chunks) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool exhausted at the device-memory limit (lower workspace_bytes to score fewer groups per batch)");
             // (h[0] = ids drawn is no measure of the need: an exhausted pool is asked again at every append)
@@ -1701,8 +1707,8 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     struct Guard { ipkgpu_parts* r; ~Guard() { if (r) ipkgpu_parts_free(r); } } guard{parts};
 
     RC_TRY(ensure(ctx, ctx->branch, (size_t)n_groups * 4));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->branch.p, pl.group_ids.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->h_branch = pl.group_ids;                          // (context-owned copy: no wait for the upload, whatever path this call leaves by)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->branch.p, ctx->h_branch.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
 
     ctx->acc_main_ms = ctx->acc_reduce_ms = ctx->acc_count_ms = ctx->acc_write_ms = ctx->acc_km_ms = 0;
     Stopwatch sw(ctx->stream);
