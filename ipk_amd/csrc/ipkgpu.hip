@@ -594,7 +594,7 @@ int launch_xp_reduce(ipkgpu_ctx* ctx, uint32_t n_gb, uint32_t S, uint64_t T, con
     else {
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
         static_assert(!COMPRESS || NB == 1 || TBL % 64 == 0, "a 64-slot block must not straddle two buckets");
-        constexpr int NT = TBL <= 16384 ? 512 : 1024;       // (1024 threads on 16000-slot tables measured slower: 24.3 vs 18.5 ms)
+        constexpr int NT = TBL <= 16384 ? 512 : 1024;       // (16000-slot tables: 1024 threads measure the same 16.5 ms as 512 since the coalesced epilogue, 256 are slower: 22.3)
         constexpr size_t lds = (size_t)TBL * 4 + (COMPRESS ? (NT / 64 + 1) * 4 : 0);
         auto kern = reduce_ranges_kernel<TBL, NT, COMPRESS>;
         if (lds > 64 * 1024)
