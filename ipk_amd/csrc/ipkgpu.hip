@@ -373,7 +373,7 @@ int launch_overflow(ipkgpu_ctx* ctx, const ScoreParams& p)
         auto kern = score_overflow_kernel<SIGMA, K, POS>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 64)));
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(32 / OVF_NW, (160 * 1024) / (lds + 64)));
         hipLaunchKernelGGL(kern, dim3(ctx->num_cu * per_cu), dim3(OVF_NW * 64), lds, ctx->stream, p);
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
@@ -440,7 +440,7 @@ int launch_stream_overflow(ipkgpu_ctx* ctx, const StreamParams& sp)
         auto kern = score_overflow_stream_kernel<SIGMA, K, TBL>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 64)));
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(32 / OVF_NW, (160 * 1024) / (lds + 64)));
         hipLaunchKernelGGL(kern, dim3(ctx->num_cu * per_cu), dim3(OVF_NW * 64), lds, ctx->stream, sp);
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;
@@ -580,7 +580,7 @@ int launch_xp_overflow(ipkgpu_ctx* ctx, const XpParams& xp)
         auto kern = score_overflow_xp_kernel<SIGMA, K, TBL, WRITE>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 64)));
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(32 / OVF_NW, (160 * 1024) / (lds + 64)));
         hipLaunchKernelGGL(kern, dim3(ctx->num_cu * per_cu), dim3(OVF_NW * 64), lds, ctx->stream, xp);
         HIP_TRY(ctx, hipGetLastError());
         return IPKGPU_OK;

@@ -194,7 +194,10 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
 // builds the two half lists, then all waves share the final cross product (it is what is big here:
 // |L| x |R| up to 4096^2) and max-reduce into the group's table with global atomics.  Every wave
 // reaches the loop exit: the queue length is fixed before this kernel starts.
-constexpr int OVF_NW = 8;
+#ifndef IPK_OVF_NW
+#define IPK_OVF_NW 8
+#endif
+constexpr int OVF_NW = IPK_OVF_NW;
 
 template <int SIGMA, int K, bool POS = false>
 __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams p)
