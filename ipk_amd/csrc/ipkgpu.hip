@@ -631,6 +631,13 @@ uint32_t stream_buckets(uint32_t sigma, uint32_t k)
 #undef M_NB
     return 0;
 }
+uint32_t stream_tbl_value(uint32_t sigma, uint32_t k)
+{
+#define M_TBLV(S_, K_) return stream_tbl<S_, K_>()
+    IPK_DISPATCH(sigma, k, M_TBLV);
+#undef M_TBLV
+    return 0;
+}
 uint32_t stream_waves(uint32_t sigma, uint32_t k)
 {
 #define M_NWV(S_, K_) return (uint32_t)stream_nw<S_, K_>()
@@ -1103,6 +1110,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     const size_t lds_bytes = use_quad ? quad_lds_bytes(pl.sigma, pl.k) : stream_lds_bytes(pl.sigma, pl.k);
     const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / SNW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
     const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
+    const uint32_t CH = chunk_pairs_rt(stream_tbl_value(pl.sigma, pl.k));      // pairs per chunk of this (sigma, k)
     const uint64_t expected_chunks = (uint64_t)((double)windows * ppw_est / CH);
 #ifndef IPK_OVF_POOL_RATIO
 #define IPK_OVF_POOL_RATIO 500

@@ -170,7 +170,7 @@ __device__ __forceinline__ void pool_store_lanes(uint2* wave_base, uint32_t byte
 // The store of a join step: of the lanes of `pass`, those whose slot v lies inside the open chunk (v < CH) store; the others
 // are returned (they wait for the bucket's next chunk).  exec = pass, then v_cmpx narrows it to the lanes inside -- the compare
 // writes exec itself, so the whole selection costs three scalar instructions.  From code that runs with ALL lanes enabled.
-__device__ __forceinline__ uint64_t pool_store_inside(uint2* wave_base, uint32_t byte_off, uint2 val, uint32_t v, uint64_t pass)
+__device__ __forceinline__ uint64_t pool_store_inside(uint2* wave_base, uint32_t byte_off, uint2 val, uint32_t v, uint64_t pass, uint32_t CH)
 {
     const unsigned long long data = ((unsigned long long)val.y << 32) | val.x;
     uint64_t outside;
@@ -183,7 +183,7 @@ __device__ __forceinline__ uint64_t pool_store_inside(uint2* wave_base, uint32_t
     return outside;
 }
 
-constexpr uint32_t QUAD_SPAN_CHUNKS = 1u << 21;   // chunks of CH * 8 = 2 KiB: 2^21 of them span 4 GiB
+constexpr uint32_t QUAD_SPAN_BYTES_LOG2 = 32;       // a wavefront's open chunks stay within 4 GiB of its base chunk
 constexpr uint32_t QUAD_SPAN_TEST = 8;            // debug_flags bit 3: rebase every 8 chunks (tests of the rebasing path)
 
 // floor(x / n) for 0 <= x < 128, 1 <= n <= 64, with rn = 1 / n to within a few ulp: (x + 0.5) / n is at least 1 / 128 away from every
@@ -198,10 +198,11 @@ __device__ __forceinline__ uint32_t div_small(float x_plus_half, float rn) { ret
 // its life.  When a new chunk lies 4 GiB or more past the base (or the pool is exhausted: then the "chunk" is the spare one at
 // id pool_cap, which absorbs the stores of a launch that is going to be repeated with a bigger pool), every open chunk is
 // closed as it is -- a descriptor may hold any count <= CH -- and the new chunk becomes the base.
-template <uint32_t NB>
+template <uint32_t NB, uint32_t CH>
 struct RowAppender {
     static constexpr uint32_t NONE = 0xFFFFFFFFu;
     static constexpr uint32_t CHUNK_BYTES = CH * 8u;
+    static constexpr uint32_t SPAN_CHUNKS = (uint32_t)((1ull << QUAD_SPAN_BYTES_LOG2) / CHUNK_BYTES);
     const StreamParams& p;
     unsigned long long* st;                 // [NB]
     uint32_t g;
@@ -249,7 +250,7 @@ struct RowAppender {
         if (nid >= p.pool_cap && lane == 0) atomicOr(p.pool_ovf, 1u);
         nid = min(nid, p.pool_cap);                                     // (not assigned under the branch: a value merged after a divergent
                                                                         //  branch counts as divergent, and the whole state would move to VGPRs)
-        if (nid - base_id >= ((p.flags & 8u) ? QUAD_SPAN_TEST : QUAD_SPAN_CHUNKS)) rebase(nid);
+        if (nid - base_id >= ((p.flags & 8u) ? QUAD_SPAN_TEST : SPAN_CHUNKS)) rebase(nid);
         const uint32_t where = (nid - base_id) * CHUNK_BYTES;
         wave_lds_sync();
         const unsigned long long old = st[b];
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
     static_assert(Q::OK, "quad kernel: DNA k = 8..12");
     constexpr uint32_t T = ipow(SIGMA, K);
     constexpr uint32_t NB = (T + TBL - 1) / TBL;
+    constexpr uint32_t CH = chunk_pairs<TBL>();
     constexpr uint32_t mulR = Q::mulR;
     static_assert(TBL % mulR == 0, "a row of the final join must stay inside one bucket");
     constexpr uint32_t CAPL = Geo<SIGMA, Q::HL, CAP>::CAPH, CAPR = Geo<SIGMA, Q::HR, CAP>::CAPH;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
     uint2* child = scratch_all + (size_t)wave * WS;                // [2][CW]
     uint2* lp = child + 2 * Q::CW;                                 // L list (codes already multiplied by mulR)
     uint2* rp = lp + CAPL;                                         // R list
-    RowAppender<NB> app{p, state_all + (size_t)wave * NB, g};
+    RowAppender<NB, CH> app{p, state_all + (size_t)wave * NB, g};
     app.init();
     unsigned long long emitted = 0;
 
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                             const uint32_t where = (uint32_t)__builtin_amdgcn_ds_bpermute(head_addr, (int)(uint32_t)(got[u] >> 32));
                             v[u] = fill + rank[u];
                             val[u] = make_uint2(a[u].x + b.x, __float_as_uint(s[u]));
-                            ovf[u] = pool_store_inside(app.base, lshl3_add(v[u], where), val[u], v[u], m[u]);
+                            ovf[u] = pool_store_inside(app.base, lshl3_add(v[u], where), val[u], v[u], m[u], CH);
                             anyo |= ovf[u];
                         }
                         while (anyo) {                                                // a bucket's chunk filled up: open a new one

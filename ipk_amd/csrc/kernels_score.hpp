@@ -279,7 +279,12 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
 //   pass 2  reduce_buckets_kernel: one workgroup per (group, bucket) max-reduces its chunks in a
 //           TBL-slot LDS table and stores the finished table slice (plain coalesced stores).
 // =================================================================================================
-constexpr uint32_t CH = 256;                 // pairs per chunk (2 KiB)
+// Pairs per chunk of the pair pool.  A bucket's open chunk is rolled every CH pairs, and a roll is ~50 instructions plus a trip
+// through the slow path of the append: at cfg2 (122 pairs per window, 64 buckets per wavefront) 512-pair chunks make the scoring kernel
+// 4 % faster than 256; with 512 buckets per wavefront (k = 11, 12: TBL = 32768) the chunks fill too slowly and 256 stays better
+// (cfg3 share: +1.7 % with 512).
+template <uint32_t TBL> constexpr uint32_t chunk_pairs() { return TBL == 16384 ? 512u : 256u; }
+inline uint32_t chunk_pairs_rt(uint32_t tbl) { return tbl == 16384 ? 512u : 256u; }
 constexpr uint32_t CHUNK_NONE = 0xFFFFFFFFu;
 constexpr uint32_t ALLOC_BATCH = 32;         // chunk ids a wavefront draws per global atomic
 constexpr uint32_t SUB = 1;                  // open chunks per (wave, bucket); >1 spreads a bucket over lane-interleaved chunks
@@ -291,7 +296,7 @@ struct StreamParams {
     const uint32_t* gm_list;       // matrix indices
     uint32_t sites, nwin, tiles_per_mat, S;   // S = segments (workgroups) per group
     float eps;
-    uint2* pool;                   // [pool_cap][CH] pairs (dense code, score bits)
+    uint2* pool;                   // [pool_cap][chunk_pairs<TBL>()] pairs (dense code, score bits)
     uint32_t pool_cap;
     uint32_t* pool_next;           // next free chunk
     unsigned long long* desc;      // [pool_cap] (group * NB + bucket) << 32 | count ; 0 = unused
@@ -403,6 +408,7 @@ __device__ __forceinline__ bool build_halves_dd(const WinCtx& c, float eps, uint
 // Per-wave appender of surviving (code, score) pairs to the pair pool: one open chunk per key bucket.
 template <uint32_t TBL, uint32_t NB>
 struct Appender {
+    static constexpr uint32_t CH = chunk_pairs<TBL>();
     const StreamParams& p;
     uint32_t* cbase;
     uint32_t* cfill;
@@ -471,6 +477,7 @@ template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_sgpr(80))) void score_stream_kernel(StreamParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t CH = chunk_pairs<TBL>();
     using TG = TileGeo<SIGMA, K, TW>;
     constexpr uint32_t T = ipow(SIGMA, K);
     constexpr uint32_t NB = (T + TBL - 1) / TBL;
@@ -593,6 +600,7 @@ template <int SIGMA, int K, uint32_t TBL>
 __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_stream_kernel(StreamParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t CH = chunk_pairs<TBL>();
     constexpr int CAPF = 1 << 30;
     constexpr uint32_t T = ipow(SIGMA, K);
     constexpr uint32_t NB = (T + TBL - 1) / TBL;
@@ -740,6 +748,7 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
                                                            uint32_t NB, uint64_t T, uint32_t* __restrict__ table,
                                                            uint32_t* __restrict__ mask, uint64_t mask_words)
 {
+    constexpr uint32_t CH = chunk_pairs<TBL>();
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
     constexpr uint32_t NWV = NT / 64;
@@ -1009,8 +1018,8 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
                         const uint2* dst = reinterpret_cast<const uint2*>(((unsigned long long)rhi << 32) | rlo);
                         const uint32_t ax = (uint32_t)__builtin_amdgcn_readlane((int)axm, (int)r);
                         const float ayr = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)a.y, (int)r));
-                        auto chunk = [&](auto CH) {
-                            constexpr int ch = decltype(CH)::value;
+                        auto chunk = [&](auto CHK) {
+                            constexpr int ch = decltype(CHK)::value;
                             if constexpr (ch < RC) {
                                 const uint32_t left = cr - (uint32_t)ch * 64u;                       // (> 0 here)
                                 const uint64_t mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
