@@ -347,3 +347,29 @@ def test_compressed_tables_keymajor_writers(engine, n_groups, n_owners):
         check_shard(db, full, sigma, k, o, n_owners)
         db.free()
     parts.free()
+
+
+@pytest.mark.parametrize("n_groups,n_owners", [(256, 1), (200, 2), (520, 1)])
+def test_compressed_writer_splits_dense_blocks(engine, n_groups, n_owners):
+    """Nearly every group holds nearly every key (4^4 keys, flat columns): a 64-key block then has far more entries than
+    the fast writer stages in LDS at once (5 632) and is done in several key ranges; with more than 256 groups also in
+    several passes.  Against the oracle database."""
+    sigma, k, sites = 4, 4, 70
+    mats = synth_matrices(n_groups, sites, sigma, 1.0, 5 + n_groups)
+    groups = np.arange(n_groups, dtype=np.uint32) + 7
+    eps = co.log_threshold(1.0, sigma, k) - 0.2
+    full, emitted = oracle_db(mats, groups, k, eps)
+    engine.set_option("variant", 4)
+    try:
+        parts = engine.score_groups_keymajor(mats, groups, k, eps, n_owners=n_owners)
+    finally:
+        engine.set_option("variant", 0)
+    assert parts.emitted == emitted
+    assert parts.num_entries > 0.5 * n_groups * sigma ** k, "the case is meant to be dense"
+    for o in range(n_owners):
+        a, b = int(parts.owner_offsets[o]), int(parts.owner_offsets[o + 1])
+        db = engine.merge_parts(sigma, k, o, n_owners, parts.counts_tensor()[o:o + 1].contiguous(),
+                                parts.entries_tensor()[a:b].contiguous(), np.zeros(1, np.uint64))
+        check_shard(db, full, sigma, k, o, n_owners)
+        db.free()
+    parts.free()
