@@ -44,10 +44,20 @@ def agree_on_pieces(mat_group, want, dist, device):
     all-reduces, identical on all ranks -- a rank never issues a collective its peers do not (uneven shards, a rank
     without groups and interleaved matrices all end in the same count everywhere)."""
     import torch
+    # the smallest wish wins (ranks with few groups want few pieces), then every rank must be able to cut that many
+    t = torch.tensor([max(1, int(want))], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    want = int(t.item())
     ok = 1 if (want <= 1 or piece_cuts(mat_group, want) is not None) else 0
     t = torch.tensor([ok], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return want if int(t.item()) == 1 and want > 1 else 1
+
+
+def default_pieces(n_groups):
+    """Pieces a rank wishes for: a scoring call costs ~0.9 ms before its first group, so small shares are
+    not cut up for the sake of hiding the exchange -- one piece per ~48 groups, at most four (cfg2 on 8 ranks: 125 groups, 2 pieces)."""
+    return int(min(4, max(1, n_groups // 48)))
 
 
 def exchange_parts(counts, entries, owner_offsets, dist, world):
@@ -109,7 +119,7 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
     """Scores this rank's groups and returns (this rank's database shard, parts) -- the state
     `_phylo_kmer_db` has after explore_kmers (db_builder.cpp:576-627), sharded by k-mer owner.
 
-    With several ranks the groups are scored in `pieces` contiguous ranges (default 4, IPK_DIST_PIECES) so that the
+    With several ranks the groups are scored in `pieces` contiguous ranges (default: default_pieces(), or IPK_DIST_PIECES) so that the
     exchange of one range's blocks runs while the next range is being scored -- only the last range's transfer is
     exposed; the merge takes pieces x world sources in the order (rank 0 piece 0, rank 0 piece 1, ..., rank 1 piece 0, ...),
     which is global group order.  All ranks use the same piece count (agree_on_pieces)."""
@@ -121,7 +131,8 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
     import torch
     mat_group = np.ascontiguousarray(mat_group, dtype=np.uint32)
     on_gpu = dist.get_backend() != "gloo"
-    want = pieces if pieces is not None else int(os.environ.get("IPK_DIST_PIECES", "4"))
+    env = os.environ.get("IPK_DIST_PIECES")
+    want = pieces if pieces is not None else (int(env) if env else default_pieces(len(np.unique(mat_group))))
     if not (overlap and hasattr(logp, "data_ptr")):
         want = 1
     n = agree_on_pieces(mat_group, max(1, want), dist, "cuda" if on_gpu else "cpu")

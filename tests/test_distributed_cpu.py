@@ -105,3 +105,8 @@ def test_ranks_agree_on_the_piece_count(tmp_path):
     mp.spawn(_agree_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
     got = [open(tmp_path / f"agree{r}.txt").read() for r in range(3)]
     assert got == ["4 1", "4 1", "4 1"]
+
+
+def test_default_pieces_follow_the_share_size():
+    from ipk_amd import distributed as D
+    assert [D.default_pieces(n) for n in (0, 1, 47, 48, 125, 250, 1000)] == [1, 1, 1, 1, 2, 4, 4]
