@@ -522,6 +522,10 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                     };
                     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
                     uint32_t i0 = 0;
+                    // three steps per trip while three remain (-2 % against two at cfg2: the trip's scalar bookkeeping is shared by
+                    // more steps; four measured slower again)
+                    using I3 = std::integral_constant<int, 3>;
+                    for (; i0 + 3 * rps <= nL; i0 += 3 * rps) trip(I3{}, std::true_type{}, i0);
                     for (; i0 + 2 * rps <= nL; i0 += 2 * rps) trip(I2{}, std::true_type{}, i0);
                     if (i0 + rps < nL) trip(I2{}, std::false_type{}, i0);
                     else if (i0 < nL) trip(I1{}, std::false_type{}, i0);
