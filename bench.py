@@ -79,6 +79,73 @@ def cold_end_to_end(cfg, n_groups, device):
     return res
 
 
+def launch_ranks(n, argv):
+    """`python3 bench.py --gpus N` without a launcher: this process touches no GPU and starts the N ranks itself -- as a CHILD
+    (`python -m torch.distributed.run`, rendezvous on 127.0.0.1), never by exec -- relays their output (rank 0's JSON line) and
+    returns their exit code.  The children carry their own watchdog; the parent's timeout is the last resort."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    limit = float(os.environ.get("IPK_BENCH_WATCHDOG_S", "1500")) + 60.0
+    pr = subprocess.Popen(cmd, env=env, start_new_session=True)       # stdout/stderr inherited: the JSON line passes straight through
+    try:
+        return pr.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        print(f"bench.py: ranks still running after {limit:.0f} s -- killing the job", file=sys.stderr)
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)                          # the session this parent created, nothing else
+        except ProcessLookupError:
+            pass
+        pr.wait()
+        return 124
+    except KeyboardInterrupt:
+        import signal
+        os.killpg(pr.pid, signal.SIGTERM)
+        return 130
+
+
+def start_watchdog():
+    """A rank that waits for ever (a peer died inside a collective, a wedged transfer) must end with a non-zero code instead
+    of holding the node: a daemon thread ends the process after IPK_BENCH_WATCHDOG_S seconds (default 1500; 0 = off)."""
+    import threading
+    limit = float(os.environ.get("IPK_BENCH_WATCHDOG_S", "1500"))
+    if limit <= 0:
+        return
+
+    def bark():
+        print(f"bench.py: watchdog -- rank {os.environ.get('RANK', '0')} not finished after {limit:.0f} s, exiting", file=sys.stderr, flush=True)
+        os._exit(124)
+    t = threading.Timer(limit, bark)
+    t.daemon = True
+    t.start()
+
+
+def dry_run(args):
+    """Launcher and watchdog rehearsal (CPU, gloo): the ranks meet, count themselves and rank 0 prints a stub line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        if os.environ.get("IPK_BENCH_DRY_HANG") == str(rank):
+            time.sleep(3600)                                   # a rank that never reaches the collective
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "n_ranks_seen": seen}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,7 +160,14 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="strong: the config's groups split over the ranks; weak: a full copy per rank")
     ap.add_argument("--e2e", type=int, default=1, help="1: also time the cold end-to-end build (N = 1 only; in a fresh child process); 0: skip")
     ap.add_argument("--e2e-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # launcher / watchdog rehearsal without a GPU (tests)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.e2e_child:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    start_watchdog()
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist
@@ -171,9 +245,10 @@ def main():
     acc = {"score": 0.0, "launches": 0.0, "total": 0.0, "compact": 0.0, "prefix": 0.0, "merge": 0.0, "main": 0.0, "reduce": 0.0, "exchange_exposed": 0.0,
            "xp_count": 0.0, "xp_write": 0.0, "km_write": 0.0}
     emitted = entries = n_keys = 0
+    exchange_kind = "none"
 
     def step(record):
-        nonlocal emitted, entries, n_keys
+        nonlocal emitted, entries, n_keys, exchange_kind
         if args.output == "group":
             r = eng.score_groups(d_logp, groups, k, eps)      # returns after the device work completed
             emitted, entries = r.emitted, r.num_entries
@@ -181,6 +256,7 @@ def main():
         else:
             db, t = D.build_db_shard(eng, d_logp, groups, k, eps, sigma, dist if world > 1 else None, world, rank)
             emitted, entries, n_keys = t.emitted, db.num_entries, db.num_keys
+            exchange_kind = getattr(t, "exchange", "none")
             if record:
                 acc["merge"] += db.time_ms()
                 acc["exchange_exposed"] += getattr(t, "exchange_exposed_ms", 0.0)
@@ -210,18 +286,22 @@ def main():
     elapsed = time.perf_counter() - t_start
     rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        tl = torch.zeros(world, dtype=torch.float64, device="cuda")
+        cdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        tl = torch.zeros(world, dtype=torch.float64, device=cdev)
         tl[rank] = acc["total"] / args.steps                       # device time of this rank's scoring calls per step
         dist.all_reduce(tl)
         rank_ms = [float(x) for x in tl.tolist()]
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        e = torch.tensor([emitted], dtype=torch.int64, device="cuda")
+        e = torch.tensor([emitted], dtype=torch.int64, device=cdev)
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
         emitted_all = int(e.item())
+        # how many ranks the transport itself was set up with: the library's RCCL communicator, or torch's process group
+        n_ranks_seen = eng.comm_world_seen() if exchange_kind == "rccl" else dist.get_world_size()
     else:
         emitted_all = emitted
+        n_ranks_seen = 1
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -272,7 +352,7 @@ def main():
             kline("km_write_kernel", per_launch("km_write"), 4.0 * (sigma ** k) * ng + e_bytes)       # dense tables in, entries out
         out = {
             "metric": "scored phylo-k-mers/sec", "value": value, "unit": "phylo-k-mers/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "exchange": exchange_kind, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: synthetic {'DNA' if sigma == 4 else 'AA'} {n_mats} extended nodes "
                                    f"({ng} branch groups x {mpg}) x {sites} sites, k={k}, omega={cfg['omega']}, "

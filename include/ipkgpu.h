@@ -80,6 +80,10 @@ const char* ipkgpu_last_error(const ipkgpu_ctx* ctx);
  * "score_xp_kernel", "score_tiles_kernel"): what IPKGPU_T_SCORE_MAIN timed. */
 const char* ipkgpu_last_main_kernel(const ipkgpu_ctx* ctx);
 
+/* Diagnostics: -1 in the shipped build; in an IPK_EXEC_ASSERT build (ipk_amd/build.py, variant "execassert") the number of
+ * times one of the kernels' exec-writing inline-asm helpers was entered with a partial exec mask (must be 0). */
+int64_t ipkgpu_debug_exec_violations(ipkgpu_ctx* ctx);
+
 /* Options: "workspace_bytes" (max bytes of per-group score tables resident at once; groups are
  * processed in batches that fit); "variant" (0 = auto: LDS max-reduce fed by the chunked pair pool, or by
  * the exact-partition passes for AA k=6; 1 = global-atomic max-reduce; 2 = force the chunked pool;
@@ -223,9 +227,16 @@ int ipkgpu_merge_parts_ptrs(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_
  * (grouped ncclSend/ncclRecv on the communicator's own stream) and returns, so the transfer runs under the next piece's
  * scoring; ipkgpu_exchange_merge waits for the pieces and merges (rank, piece)-ordered sources into this rank's shard.
  * All ranks must use the same number of pieces.  RCCL is loaded at run time: IPKGPU_ERR_NODEVICE if it is not there.
+ * Failure must be symmetric, or the healthy ranks wait for ever inside a collective: everything that can fail on one rank
+ * alone (loading RCCL, the exchange stream and buffers) is done by ipkgpu_comm_prepare, BEFORE the collective
+ * ncclCommInitRank inside ipkgpu_comm_init -- the ranks agree on the prepare results first (an all-reduce by whatever carried
+ * the id) and enter ipkgpu_comm_init only if all succeeded.  A rank whose ipkgpu_exchange_begin fails aborts the communicator
+ * (ncclCommAbort), which makes its peers' pending transfers fail instead of hang; it should then exit non-zero.
  * CPU analogue: branch_group.cpp:45-70,104-107 (merge_batch, kmer_batch), db_builder.cpp:392-458 (merge_stage2). */
 typedef struct ipkgpu_xfer ipkgpu_xfer;
+int ipkgpu_comm_available(void);                          /* IPKGPU_OK if RCCL can be loaded in this process (no GPU call) */
 int ipkgpu_comm_unique_id(uint8_t* id128);
+int ipkgpu_comm_prepare(ipkgpu_ctx* ctx, int world);       /* the local, non-collective half of the set-up (idempotent) */
 int ipkgpu_comm_init(ipkgpu_ctx* ctx, const uint8_t* id128, int rank, int world);
 int ipkgpu_comm_rank(const ipkgpu_ctx* ctx);
 int ipkgpu_comm_world(const ipkgpu_ctx* ctx);
@@ -261,8 +272,9 @@ float ipkgpu_score_threshold(float omega, uint32_t sigma, uint32_t k);
  *   total_num_groups  N = node count of the original tree (db_builder.cpp:261)
  *   threshold         score_threshold(omega, k), NOT its log (db_builder.cpp:260)
  * Filter values are per k-mer, so a shard is filtered independently of the other owners.
- * Double arithmetic on the device: agrees with the reference formula to ~1e-13 relative (parallel
- * summation order, device pow/log2), not bit for bit.
+ * Double arithmetic on the device, the entries' terms ADDED IN ENTRY ORDER (the association of the reference's two
+ * sequential loops, filter.cpp:60-119): the float filter values and the k-mer order equal a sequential host evaluation;
+ * only the last bit of the device's pow / log2 could differ from the host's libm.
  */
 int ipkgpu_db_filter_mif0(ipkgpu_ctx* ctx, ipkgpu_db* db, uint64_t total_num_groups, float threshold);
 /* host copies: filter value per k-mer (as the float i2l::kmer_fv stores, and in double), and the

@@ -31,5 +31,25 @@ def build(force=False, verbose=False):
     return LIB
 
 
+VARIANTS = {"execassert": ["-DIPK_EXEC_ASSERT=1"]}          # diagnostic builds of the same library (tests only)
+
+
+def build_variant(name, force=False, verbose=False):
+    """ipk_amd/_variants/v_<name>.so: the library with extra defines; loaded through IPKGPU_LIB by the test that needs it."""
+    vdir = os.path.join(HERE, "_variants")
+    os.makedirs(vdir, exist_ok=True)
+    target = os.path.join(vdir, f"v_{name}.so")
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    if force or _stale(target, srcs + [os.path.join(HERE, "..", "include", "ipkgpu.h"), os.path.abspath(__file__)]):
+        units = [s for s in srcs if s.endswith((".hip", ".cpp"))]
+        cmd = [HIPCC] + FLAGS + VARIANTS[name] + ["-o", target] + units
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return target
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    for v in VARIANTS:
+        print(build_variant(v, force="--force" in sys.argv, verbose=True))

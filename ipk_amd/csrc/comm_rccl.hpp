@@ -18,6 +18,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;          // optional: tears a communicator down without a collective
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -34,6 +35,7 @@ struct RcclApi {
         GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
@@ -48,7 +50,8 @@ RcclApi g_rccl;
 }  // namespace
 
 struct ipkgpu_comm {
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;            // null while only prepared (ipkgpu_comm_prepare) or after a failed exchange
+    bool dead = false;                    // a collective of this communicator failed on this rank: aborted, unusable
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;         // the exchange runs beside the scoring stream
     uint64_t* d_sizes = nullptr;          // [2][world]: entries sent to / received from every peer
@@ -82,7 +85,7 @@ static void ipkgpu_comm_release(ipkgpu_ctx* ctx)
 {
     ipkgpu_comm* c = ctx->comm;
     if (!c) return;
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (c->stream && !c->dead) { (void)hipStreamSynchronize(c->stream); }
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->d_sizes) (void)hipFree(c->d_sizes);
@@ -104,29 +107,57 @@ int ipkgpu_comm_unique_id(uint8_t* id128)
     return IPKGPU_OK;
 }
 
-int ipkgpu_comm_init(ipkgpu_ctx* ctx, const uint8_t* id128, int rank, int world)
+// Everything of the communicator set-up that can fail on ONE rank alone -- loading RCCL, the exchange stream, the size
+// buffers -- happens here, BEFORE the collective ncclCommInitRank: the ranks agree that every one of them got this far (the
+// caller all-reduces the return codes) and only then enter ipkgpu_comm_init, so no rank is left waiting inside the collective
+// for a peer that has already given up.
+int ipkgpu_comm_available(void)
+{
+    if (!g_rccl.load()) return fail(nullptr, IPKGPU_ERR_NODEVICE, "%s", g_rccl.err.c_str());
+    return IPKGPU_OK;
+}
+
+int ipkgpu_comm_prepare(ipkgpu_ctx* ctx, int world)
 {
     if (!ctx) return IPKGPU_ERR_INVALID;
-    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(ctx, IPKGPU_ERR_INVALID, "bad communicator arguments");
-    if (ctx->comm) return fail(ctx, IPKGPU_ERR_INVALID, "communicator already initialised");
+    if (world < 1) return fail(ctx, IPKGPU_ERR_INVALID, "bad communicator arguments");
+    if (ctx->comm) return ctx->comm->comm ? fail(ctx, IPKGPU_ERR_INVALID, "communicator already initialised") : IPKGPU_OK;
     if (!g_rccl.load()) return fail(ctx, IPKGPU_ERR_NODEVICE, "%s", g_rccl.err.c_str());
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ipkgpu_comm* c = new (std::nothrow) ipkgpu_comm();
     if (!c) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
-    c->rank = rank; c->world = world;
-    ncclUniqueId id;
-    memcpy(id.internal, id128, 128);
-    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
-    if (r != ncclSuccess) { delete c; return fail(ctx, IPKGPU_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+    c->world = world;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_sizes, (size_t)2 * world * 8);
-    if (e != hipSuccess) { (void)g_rccl.CommDestroy(c->comm); if (c->stream) (void)hipStreamDestroy(c->stream); delete c; HIP_TRY(ctx, e); }
+    if (e != hipSuccess) { if (c->stream) (void)hipStreamDestroy(c->stream); delete c; HIP_TRY(ctx, e); }
     ctx->comm = c;
     return IPKGPU_OK;
 }
 
-int ipkgpu_comm_rank(const ipkgpu_ctx* ctx) { return ctx && ctx->comm ? ctx->comm->rank : 0; }
-int ipkgpu_comm_world(const ipkgpu_ctx* ctx) { return ctx && ctx->comm ? ctx->comm->world : 1; }
+int ipkgpu_comm_init(ipkgpu_ctx* ctx, const uint8_t* id128, int rank, int world)
+{
+    if (!ctx) return IPKGPU_ERR_INVALID;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(ctx, IPKGPU_ERR_INVALID, "bad communicator arguments");
+    if (ctx->comm && ctx->comm->comm) return fail(ctx, IPKGPU_ERR_INVALID, "communicator already initialised");
+    if (ctx->comm && ctx->comm->world != world) return fail(ctx, IPKGPU_ERR_INVALID, "prepared for another world size");
+    const int rp = ipkgpu_comm_prepare(ctx, world);
+    if (rp != IPKGPU_OK) return rp;
+    ipkgpu_comm* c = ctx->comm;
+    c->rank = rank;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(id.internal, id128, 128);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        ipkgpu_comm_release(ctx);
+        return fail(ctx, IPKGPU_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+    }
+    return IPKGPU_OK;
+}
+
+int ipkgpu_comm_rank(const ipkgpu_ctx* ctx) { return ctx && ctx->comm && ctx->comm->comm ? ctx->comm->rank : 0; }
+int ipkgpu_comm_world(const ipkgpu_ctx* ctx) { return ctx && ctx->comm && ctx->comm->comm ? ctx->comm->world : 1; }
 
 void ipkgpu_xfer_free(ipkgpu_xfer* x)
 {
@@ -142,14 +173,28 @@ void ipkgpu_xfer_free(ipkgpu_xfer* x)
 // Starts the exchange of one piece: block o of `parts` (counts row o, entries [owner_off[o], owner_off[o+1])) goes to rank o.
 // Returns after the transfers have been ENQUEUED on the communicator's stream; `parts` must stay alive until
 // ipkgpu_exchange_merge.  The entry counts travel first (one u64 per peer) because the receive sizes must be known on the host.
+static int exchange_begin_impl(ipkgpu_ctx* ctx, ipkgpu_comm* c, ipkgpu_parts* parts, ipkgpu_xfer** out);
+
 int ipkgpu_exchange_begin(ipkgpu_ctx* ctx, ipkgpu_parts* parts, ipkgpu_xfer** out)
 {
     if (!ctx) return IPKGPU_ERR_INVALID;
     if (!out) return fail(ctx, IPKGPU_ERR_INVALID, "null out pointer");
     *out = nullptr;
     ipkgpu_comm* c = ctx->comm;
-    if (!c) return fail(ctx, IPKGPU_ERR_INVALID, "no communicator: call ipkgpu_comm_init first");
+    if (!c || !c->comm) return fail(ctx, IPKGPU_ERR_INVALID, c && c->dead ? "the communicator was aborted after a failed exchange" : "no communicator: call ipkgpu_comm_init first");
     if (!parts || parts->ctx != ctx || parts->n_owners != (uint32_t)c->world) return fail(ctx, IPKGPU_ERR_INVALID, "parts must be split for n_owners = world size");
+    const int rc = exchange_begin_impl(ctx, c, parts, out);
+    if (rc != IPKGPU_OK) {
+        // a rank that leaves the exchange half way must not leave its peers waiting in the grouped Send/Recv: abort the
+        // communicator (their calls then fail instead of hanging); the caller exits non-zero and the launcher ends the job
+        if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm); else (void)g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr; c->dead = true;
+    }
+    return rc;
+}
+
+static int exchange_begin_impl(ipkgpu_ctx* ctx, ipkgpu_comm* c, ipkgpu_parts* parts, ipkgpu_xfer** out)
+{
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t P = (uint32_t)c->world;
     ipkgpu_xfer* x = new (std::nothrow) ipkgpu_xfer();
@@ -205,7 +250,7 @@ int ipkgpu_exchange_merge(ipkgpu_ctx* ctx, ipkgpu_xfer* const* xfers, uint32_t n
     if (!out) return fail(ctx, IPKGPU_ERR_INVALID, "null out pointer");
     *out = nullptr;
     ipkgpu_comm* c = ctx->comm;
-    if (!c || !xfers || n_pieces == 0) return fail(ctx, IPKGPU_ERR_INVALID, "bad exchange arguments");
+    if (!c || !c->comm || !xfers || n_pieces == 0) return fail(ctx, IPKGPU_ERR_INVALID, "bad exchange arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t j = 0; j < n_pieces; ++j) {

@@ -59,6 +59,19 @@ __device__ __forceinline__ uint32_t to_sgpr(uint32_t x)
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
+// The exec-writing asm helpers below (store8_lanes, pool_store_lanes, pool_store_inside, km_write_c's LDS scatter) end with
+// `s_mov_b64 exec, -1`: they are only correct from code that runs with all 64 lanes enabled.  That holds by construction
+// (uniform control flow in full wavefronts) but nothing in the language says so -- a compiler that structurises one of the
+// surrounding loops as divergent would break them silently.  The IPK_EXEC_ASSERT build (ipk_amd/build.py: variant
+// "execassert", run by tests/test_gpu_parity.py::test_exec_assert_build) counts every call that is entered with a partial
+// exec mask; ipkgpu_debug_exec_violations() reads the count.  The shipped build compiles the check away.
+#ifdef IPK_EXEC_ASSERT
+__device__ unsigned int g_exec_violations;
+#define IPK_ASSERT_FULL_EXEC() do { if (__builtin_amdgcn_ballot_w64(true) != ~0ull) atomicAdd(&g_exec_violations, 1u); } while (0)
+#else
+#define IPK_ASSERT_FULL_EXEC() ((void)0)
+#endif
+
 // One 8-byte record per lane of `mask` to uniform_base + byte_off (+ IMM bytes): the store form with a scalar base and a 32-bit
 // lane offset, the lanes selected by writing exec directly -- from code that runs with ALL lanes enabled (uniform control flow
 // in full wavefronts).  Two scalar instructions around the store instead of compare / and-saveexec / branch / restore.
@@ -66,6 +79,7 @@ template <int IMM = 0>
 __device__ __forceinline__ void store8_lanes(const void* uniform_base, uint32_t byte_off, uint32_t x, uint32_t y, uint64_t mask)
 {
     u32x2_t data; data.x = x; data.y = y;
+    IPK_ASSERT_FULL_EXEC();
     asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2 offset:%4\n\ts_mov_b64 exec, -1"
                  : : "v"(byte_off), "v"(data), "s"(uniform_base), "s"(mask), "n"(IMM) : "memory");
 }

@@ -2119,6 +2119,21 @@ extern "C" {
 
 const char* ipkgpu_db_write_last_error(void) { return g_write_err.c_str(); }
 const char* ipkgpu_last_main_kernel(const ipkgpu_ctx* ctx) { return ctx ? ctx->main_kernel : ""; }
+
+// Diagnostics: calls of the exec-writing asm helpers entered with a partial exec mask since the library was loaded
+// (IPK_EXEC_ASSERT builds only; -1 in the shipped build, which compiles the check away).
+int64_t ipkgpu_debug_exec_violations(ipkgpu_ctx* ctx)
+{
+#ifdef IPK_EXEC_ASSERT
+    if (!ctx || hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -2;
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(ipkgpu::g_exec_violations), sizeof v) != hipSuccess) return -2;
+    return (int64_t)v;
+#else
+    (void)ctx;
+    return -1;
+#endif
+}
 double ipkgpu_db_write_time_s(const ipkgpu_ctx* ctx, int which)
 {
     if (!ctx) return 0;

@@ -435,13 +435,18 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
                         u32x2_t e; e.x = rowbr[wave][b8 + u]; e.y = val[b8 + u];
                         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.x);
                         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.y);
+                        IPK_ASSERT_FULL_EXEC();
                         asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, -1"
-                                     : "+v"(pb) : "v"(e), "s"(((uint64_t)hi << 32) | lo));
+                                     : "+v"(pb) : "v"(e), "s"(((uint64_t)hi << 32) | lo) : "memory");
                     }
                 }
             }
         };
         if (pm == ~0ull) scatter(std::true_type{}, posb); else scatter(std::false_type{}, posb);
+        // the scatter's ds_write_b64 live inside asm statements, which the compiler's waitcnt pass does not count: without this
+        // wait the barrier below is a bare s_barrier, and s_barrier does not wait for outstanding LDS operations -- the other
+        // wavefronts could read `out` before this one's writes have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
 
         // copy out

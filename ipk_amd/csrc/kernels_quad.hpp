@@ -163,6 +163,7 @@ __device__ __forceinline__ uint32_t lshl3_add(uint32_t x, uint32_t y)
 __device__ __forceinline__ void pool_store_lanes(uint2* wave_base, uint32_t byte_off, uint2 val, uint64_t mask)
 {
     const unsigned long long data = ((unsigned long long)val.y << 32) | val.x;
+    IPK_ASSERT_FULL_EXEC();
     asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_mov_b64 exec, -1"
                  : : "v"(byte_off), "v"(data), "s"(wave_base), "s"(mask) : "memory");
 }
@@ -174,6 +175,7 @@ __device__ __forceinline__ uint64_t pool_store_inside(uint2* wave_base, uint32_t
 {
     const unsigned long long data = ((unsigned long long)val.y << 32) | val.x;
     uint64_t outside;
+    IPK_ASSERT_FULL_EXEC();
     asm volatile("s_mov_b64 exec, %5\n\t"
                  "v_cmpx_gt_u32_e32 vcc, %6, %4\n\t"
                  "global_store_dwordx2 %1, %2, %3\n\t"

@@ -88,13 +88,28 @@ def exchange_parts(counts, entries, owner_offsets, dist, world):
 
 def init_native_comm(engine, dist, world, rank):
     """Creates the library's RCCL communicator on every rank (id from rank 0, carried by torch.distributed).
-    Returns False -- on ALL ranks alike -- when RCCL is not usable (gloo rehearsal, several ranks on one GPU, no library)."""
+    Returns False -- on ALL ranks alike -- when RCCL is not usable (gloo rehearsal, several ranks on one GPU, no library).
+
+    Failure is kept symmetric: ncclCommInitRank is a collective, so a rank that gave up before it would leave its peers
+    waiting inside it.  Everything that can fail on one rank alone (loading RCCL, the exchange stream and buffers:
+    comm_prepare) comes first and the ranks agree on its outcome with an all-reduce; only then does rank 0 draw the id and
+    every rank enter comm_init.  A failure inside the collective itself raises on the rank that sees it (its process exits
+    non-zero, the launcher tears the job down); bench.py's watchdog bounds the wait of the others."""
     import torch
     if getattr(engine, "comm_world", 1) == world and world > 1:
         return True
     if os.environ.get("IPK_DIST_NATIVE", "1") == "0" or dist.get_backend() != "nccl":
         return False
     dev = torch.device("cuda", torch.cuda.current_device())
+    ok = 1
+    try:
+        engine.comm_prepare(world)
+    except Exception:
+        ok = 0
+    t = torch.tensor([ok], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) != 1:
+        return False
     buf = torch.zeros(129, dtype=torch.uint8, device=dev)
     if rank == 0:
         try:
@@ -105,14 +120,12 @@ def init_native_comm(engine, dist, world, rank):
     dist.broadcast(buf, 0)
     if int(buf[128].item()) != 1:
         return False
-    ok = 1
-    try:
-        engine.comm_init(bytes(buf[:128].cpu().numpy().tobytes()), rank, world)
-    except Exception:
-        ok = 0
-    t = torch.tensor([ok], dtype=torch.int64, device=dev)
+    engine.comm_init(bytes(buf[:128].cpu().numpy().tobytes()), rank, world)      # collective: raises, never "returns False"
+    t = torch.tensor([engine.comm_world_seen()], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return int(t.item()) == 1
+    if int(t.item()) != world:
+        raise RuntimeError(f"RCCL communicator saw {int(t.item())} ranks, expected {world}")
+    return True
 
 
 def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=1, rank=0, overlap=True, pieces=None):
@@ -164,6 +177,7 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
         exposed = (time.perf_counter() - t_wait) * 1e3
     first = scored[0]
     first.exchange_exposed_ms = exposed
+    first.exchange = "rccl" if native else "torch"      # in-library grouped ncclSend/ncclRecv | torch.distributed transport
     for pj in scored[1:]:
         first.emitted += pj.emitted
         for which in range(10):                                          # IPKGPU_T_* selectors

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "ipkgpu_result_num_groups", "ipkgpu_result_group_ids", "ipkgpu_result_offsets",
     "ipkgpu_result_emitted", "ipkgpu_result_keys", "ipkgpu_result_scores",
     "ipkgpu_result_keys_device", "ipkgpu_result_scores_device", "ipkgpu_result_time_ms",
-    "ipkgpu_result_free", "ipkgpu_score_groups_positions", "ipkgpu_result_positions",
+    "ipkgpu_result_free", "ipkgpu_score_groups_positions", "ipkgpu_result_positions", "ipkgpu_debug_exec_violations",
 ]
 
 
@@ -59,6 +59,8 @@ def load_library():
     L.ipkgpu_last_error.argtypes = [C.c_void_p]
     L.ipkgpu_last_main_kernel.restype = C.c_char_p
     L.ipkgpu_last_main_kernel.argtypes = [C.c_void_p]
+    L.ipkgpu_debug_exec_violations.restype = C.c_int64
+    L.ipkgpu_debug_exec_violations.argtypes = [C.c_void_p]
     L.ipkgpu_set_option.restype = C.c_int
     L.ipkgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.ipkgpu_log_threshold.restype = C.c_float
@@ -308,6 +310,10 @@ def _bind_keymajor(L):
     L.ipkgpu_comm_unique_id.argtypes = [C.c_void_p]
     L.ipkgpu_comm_init.restype = C.c_int
     L.ipkgpu_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.ipkgpu_comm_available.restype = C.c_int
+    L.ipkgpu_comm_available.argtypes = []
+    L.ipkgpu_comm_prepare.restype = C.c_int
+    L.ipkgpu_comm_prepare.argtypes = [C.c_void_p, C.c_int]
     for n in ("ipkgpu_comm_rank", "ipkgpu_comm_world"):
         getattr(L, n).restype = C.c_int
         getattr(L, n).argtypes = [C.c_void_p]
@@ -369,6 +375,7 @@ ABI_SYMBOLS += [
     "ipkgpu_db_filter_time_ms",
     "ipkgpu_merge_parts_ptrs", "ipkgpu_comm_unique_id", "ipkgpu_comm_init", "ipkgpu_comm_rank", "ipkgpu_comm_world",
     "ipkgpu_exchange_begin", "ipkgpu_exchange_merge", "ipkgpu_xfer_exposed_ms", "ipkgpu_xfer_free",
+    "ipkgpu_comm_available", "ipkgpu_comm_prepare",
 ]
 
 
@@ -575,6 +582,21 @@ def _comm_unique_id(self):
     return bytes(buf)
 
 
+def _comm_prepare(self, world):
+    """The local half of the communicator set-up (RCCL loaded, exchange stream and size buffers allocated): everything that
+    can fail on one rank alone, done before the collective comm_init so that the ranks can agree on it first."""
+    _bind_keymajor(self._lib)
+    rc = self._lib.ipkgpu_comm_prepare(self._h, world)
+    if rc != 0:
+        raise self._err(rc)
+
+
+def _comm_world_seen(self):
+    """World size of the library's RCCL communicator (1 without one): what RCCL itself was initialised with."""
+    _bind_keymajor(self._lib)
+    return int(self._lib.ipkgpu_comm_world(self._h))
+
+
 def _comm_init(self, unique_id, rank, world):
     """RCCL communicator of this context (the id's 128 bytes come from rank 0's comm_unique_id)."""
     _bind_keymajor(self._lib)
@@ -622,6 +644,8 @@ Engine.db_from_parts = _db_from_parts
 Engine.merge_parts_ptrs = _merge_parts_ptrs
 Engine.comm_unique_id = _comm_unique_id
 Engine.comm_init = _comm_init
+Engine.comm_prepare = _comm_prepare
+Engine.comm_world_seen = _comm_world_seen
 Engine.exchange_begin = _exchange_begin
 Engine.exchange_merge = _exchange_merge
 Engine.comm_world = 1

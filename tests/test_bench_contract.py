@@ -43,3 +43,50 @@ def test_bench_weak_mode_and_group_output():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["scaling"] == "weak" and d["value"] > 0 and "e2e" not in d
+
+
+def _run_bench(argv, env=None, timeout=300):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus N` with no launcher around it (the driver's command form): the parent starts N ranks as
+    children, relays rank 0's line and their exit code.  CPU rehearsal of the launcher (--dry-run: gloo, no GPU call)."""
+    out = _run_bench(["--gpus", "2", "--dry-run"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2
+
+
+def test_bench_watchdog_ends_a_hung_job_with_an_error():
+    """A rank that never reaches the collective: its peers' watchdog ends the job non-zero instead of waiting for ever."""
+    import time
+    t0 = time.time()
+    out = _run_bench(["--gpus", "2", "--dry-run"], env={"IPK_BENCH_DRY_HANG": "1", "IPK_BENCH_WATCHDOG_S": "8"}, timeout=200)
+    assert out.returncode != 0
+    assert time.time() - t0 < 150
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_self_launched():
+    """The N > 1 bench path end to end on a one-GPU box: both ranks pinned to GPU 0, gloo transport (RCCL refuses two ranks
+    on one device), started by bench.py itself."""
+    out = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--groups", "12"],
+                     env={"IPK_BENCH_DEVICE": "0", "IPK_DIST_BACKEND": "gloo"}, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["exchange"] == "torch" and d["value"] > 0
+    assert d["scaling"] == "strong" and "roofline" in d
+    # strong scaling: the two ranks together scored what one rank scores alone
+    one = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--groups", "12", "--cpu-groups", "0", "--e2e", "0"], timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_ranks_seen"] == 1 and d1["exchange"] == "none"
+    assert round(d["value"] * d["ms_per_step"]) == round(d1["value"] * d1["ms_per_step"])

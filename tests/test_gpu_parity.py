@@ -351,3 +351,48 @@ def test_quad_store_window_rebasing(engine, k):
             assert np.array_equal(gk, ref[g][0]) and np.array_equal(gs.view(np.uint32), ref[g][1].view(np.uint32)), (k, pool_chunks, g)
         assert res.emitted == sum(r[2] for r in ref)
         res.free()
+
+
+_EXEC_ASSERT_SCRIPT = r"""
+import sys, numpy as np
+import ipk_amd
+from ipk_amd.synth import synth_matrices
+from oracle import ipk_oracle as co
+eng = ipk_amd.Engine(0)
+assert eng._lib.ipkgpu_debug_exec_violations(eng._h) == 0, "not an IPK_EXEC_ASSERT build"
+cases = [(4, 10, 6, 300, 0.05), (4, 12, 2, 120, 0.1), (4, 8, 4, 200, 0.1), (20, 6, 4, 40, 0.03), (20, 3, 4, 60, 0.03), (4, 10, 4, 200, 1.0)]
+for sigma, k, n, sites, alpha in cases:
+    mats = synth_matrices(n, sites, sigma, alpha, 77 + k)
+    groups = np.repeat(np.arange(n // 2, dtype=np.uint32) + 3, 2)
+    eps = co.log_threshold(1.5, sigma, k)
+    res = eng.score_groups(mats, groups, k, eps)            # group-major: scoring kernels + LDS reduce + CSR writers
+    tot = 0
+    for gi in range(n // 2):
+        keys, scores, emitted = co.explore_group(mats[2 * gi:2 * gi + 2], k, eps)
+        gk, gs = res.group(gi)
+        assert np.array_equal(gk, keys) and np.array_equal(gs.view(np.uint32), scores.view(np.uint32))
+        tot += emitted
+    assert res.emitted == tot
+    res.free()
+    parts = eng.score_groups_keymajor(mats, groups, k, eps, n_owners=1)   # key-major: km_write / km_write_c
+    assert parts.emitted == tot
+    parts.free()
+v = eng._lib.ipkgpu_debug_exec_violations(eng._h)
+print("EXEC_VIOLATIONS", v)
+sys.exit(0 if v == 0 else 3)
+"""
+
+
+def test_exec_assert_build():
+    """The inline-asm helpers that write `exec` (store8_lanes, pool_store_lanes, pool_store_inside, km_write_c's LDS scatter)
+    restore it to all ones: correct only when entered with every lane enabled.  The IPK_EXEC_ASSERT build of the library
+    counts entries with a partial mask; the count must stay 0 across every kernel family, results still bit-exact."""
+    import subprocess
+    import sys
+    from ipk_amd import build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = B.build_variant("execassert")
+    out = subprocess.run([sys.executable, "-c", _EXEC_ASSERT_SCRIPT], capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(os.environ, IPKGPU_LIB=lib, PYTHONPATH=root))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "EXEC_VIOLATIONS 0" in out.stdout
