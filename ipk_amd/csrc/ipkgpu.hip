@@ -492,6 +492,14 @@ template <int SIGMA, int K> constexpr bool quad_ok() { return QuadGeo<SIGMA, K>:
 #endif
 template <int SIGMA, int K> constexpr int quad_nw() { return K <= 10 ? IPK_QNW : IPK_QNW12; }
 template <int SIGMA, int K> constexpr int quad_tw() { return K <= 10 ? IPK_QTW : IPK_QTW12; }
+// the final join with one row of L per lane (kernels_quad.hpp, ROWLANE): k = 11, 12
+#ifndef IPK_QROWLANE12
+#define IPK_QROWLANE12 1
+#endif
+#ifndef IPK_QROWLANE
+#define IPK_QROWLANE 0
+#endif
+template <int SIGMA, int K> constexpr bool quad_rowlane() { return K <= 10 ? IPK_QROWLANE != 0 : IPK_QROWLANE12 != 0; }
 template <int SIGMA, int K> size_t quad_lds()
 {
     if constexpr (!quad_ok<SIGMA, K>()) return 0;
@@ -512,7 +520,7 @@ int launch_quad_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
         constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
         constexpr int QNW = quad_nw<SIGMA, K>(), QTW = quad_tw<SIGMA, K>();
         const size_t lds = quad_lds<SIGMA, K>();
-        auto kern = score_quad_kernel<SIGMA, K, CAP, QTW, QNW, TBL, COUNT_ONLY>;
+        auto kern = score_quad_kernel<SIGMA, K, CAP, QTW, QNW, TBL, COUNT_ONLY, quad_rowlane<SIGMA, K>()>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(QNW * 64), lds, ctx->stream, sp);

@@ -271,9 +271,87 @@ struct RowAppender {
     }
 };
 
+// The appender of the row-per-lane final join (ROWLANE, k = 11, 12): one {reserved pairs, chunk id} word pair per key bucket.
+// Every lane (= one row of L) reserves its whole run of pairs with ONE 64-bit LDS atomic, and a run never straddles two
+// chunks: when a bucket's reservations pass the chunk's end, roll_at() closes the chunk at the first run that does not fit
+// (a descriptor may hold any count <= CH) and that run and the ones behind it start a new chunk.  Lanes address the pool
+// with their own 64-bit pointers, so chunk ids need no common base (no RowAppender::rebase).
+template <uint32_t NB, uint32_t CH>
+struct LaneAppender {
+    static constexpr uint32_t NONE = 0xFFFFFFFFu;
+    const StreamParams& p;
+    unsigned long long* st;                 // [NB]  low word = pairs reserved in the open chunk, high word = its id
+    uint32_t g;
+    uint32_t chunk_next = 0, chunk_end = 0;
+
+    __device__ __forceinline__ void init()
+    {
+        for (uint32_t b = lane_id(); b < NB; b += 64) st[b] = ((unsigned long long)NONE << 32) | (unsigned long long)CH;   // "full": the first run rolls
+    }
+    // Bucket b's open chunk ends at x pairs (x <= CH: the start of the first run that does not fit); the runs from x on move to
+    // a new chunk, whose id is returned (should they exceed that chunk too, the caller finds the next crossing run there).
+    __device__ __forceinline__ uint32_t roll_at(uint32_t b, uint32_t x)
+    {
+        const uint32_t lane = lane_id();
+        if (chunk_next == chunk_end) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(p.pool_next, ALLOC_BATCH);
+            chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            chunk_end = chunk_next + ALLOC_BATCH;
+        }
+        uint32_t nid = to_sgpr(chunk_next);
+        chunk_next = nid + 1;
+        if (nid >= p.pool_cap && lane == 0) atomicOr(p.pool_ovf, 1u);
+        nid = min(nid, p.pool_cap);                                     // (exhausted pool: the spare chunk absorbs the stores; the launch is redone)
+        wave_lds_sync();
+        const unsigned long long old = st[b];
+        wave_lds_sync();
+        if (lane == 0) {
+            const uint32_t oid = (uint32_t)(old >> 32);
+            if (oid < p.pool_cap) p.desc[oid] = ((unsigned long long)(g * NB + b) << 32) | (unsigned long long)x;
+            st[b] = ((unsigned long long)nid << 32) | (unsigned long long)((uint32_t)old - x);
+        }
+        wave_lds_sync();
+        return nid;
+    }
+    __device__ __forceinline__ void close()
+    {
+        wave_lds_sync();
+        for (uint32_t b = lane_id(); b < NB; b += 64) {
+            const unsigned long long s = st[b];
+            const uint32_t id = (uint32_t)(s >> 32);
+            if (id < p.pool_cap) p.desc[id] = ((unsigned long long)(g * NB + b) << 32) | (unsigned long long)min((uint32_t)s, CH);
+        }
+    }
+};
+
+// One column of the row-per-lane join's second pass: the lanes with s > eps (pk_compute.cpp:91) store their pair (x, s) at
+// their row's cursor and advance it by one pair.  The compare writes exec itself, so test + store + advance + restore are four
+// instructions (a compare into a scalar mask, exec written from it, an add-with-carry on a pair counter and the address
+// arithmetic were nine).  From code that runs with ALL lanes enabled.
+__device__ __forceinline__ void store_pair_if_gt(unsigned long long& cursor, uint32_t x, float s, float eps)
+{
+    u32x2_t data; data.x = x; data.y = __float_as_uint(s);
+    IPK_ASSERT_FULL_EXEC();
+    // (no "memory" clobber: nothing in these kernels reads the pool back, and the clobber would pin the LDS reads around it)
+    asm volatile("v_cmpx_lt_f32_e32 vcc, %3, %2\n\t"
+                 "global_store_dwordx2 %0, %1, off\n\t"
+                 "v_lshl_add_u64 %0, %0, 0, 8\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(cursor) : "v"(data), "v"(s), "s"(eps) : "vcc");
+}
+
 // COUNT_ONLY: the pool-sizing pre-pass of a context's first call -- same windows, same lists, the final join only counts its
 // survivors (nothing is reserved or stored); a separate instantiation so that it shows under its own name in a kernel trace.
-template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL, bool COUNT_ONLY = false>
+//
+// ROWLANE (k = 11, 12): the final join with one row of L per LANE.  At k = 12 a window's half lists hold ~49 x ~43 entries and a
+// quarter of the candidate pairs pass: the candidate-per-lane join above spends ~49 steps of ~26 instructions per window, each
+// with its own LDS atomic + ds_bpermute round trip, at 9 wavefronts per CU (nothing hides the latency).  Here lane i keeps row
+// a_i; a block of <= CB entries of R is walked by COLUMN -- b_j is a broadcast LDS read (every lane the same address), one
+// add + compare + add-with-carry per column counts the row's passing pairs (pass 1); every row reserves its run with one
+// LDS atomic (one round trip per (row block, column block), not per step); pass 2 walks the columns again and the passing
+// lanes store to their run, `row pointer + 8 * pairs so far`.  Same float operations, same pairs (pk_compute.cpp:90-91).
+template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL, bool COUNT_ONLY = false, bool ROWLANE = false>
 __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -304,7 +382,8 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
     uint2* child = scratch_all + (size_t)wave * WS;                // [2][CW]
     uint2* lp = child + 2 * Q::CW;                                 // L list (codes already multiplied by mulR)
     uint2* rp = lp + CAPL;                                         // R list
-    RowAppender<NB, CH> app{p, state_all + (size_t)wave * NB, g};
+    using Appender = std::conditional_t<ROWLANE, LaneAppender<NB, CH>, RowAppender<NB, CH>>;
+    Appender app{p, state_all + (size_t)wave * NB, g};
     app.init();
     unsigned long long emitted = 0;
 
@@ -432,6 +511,75 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                 if (nL == 0 || nR == 0) continue;
                 wave_lds_sync();
                 if (p.flags & 4u) { emitted += nL + nR; continue; }                 // diagnostics: list building only
+                if constexpr (ROWLANE) {
+                    // ---- final join, one row of L per lane ---------------------------------------------------------------
+                    constexpr uint32_t CB = 64;                                       // columns per round: a row's run is <= 64 <= CH pairs
+                    static_assert(CB <= CH, "row-per-lane join: a run must fit a chunk");
+                    for (uint32_t ib = 0; ib < nL; ib += 64) {
+                        const uint2 a = lp[ib + lane];                               // (rows past nL read on into R: they never pass, ay = -inf)
+                        const bool rv = ib + lane < nL;
+                        const float ay = rv ? __uint_as_float(a.y) : -__builtin_inff();
+                        const uint32_t bk = a.x / TBL;
+                        for (uint32_t jb = 0; jb < nR; jb += CB) {
+                            const uint32_t nc = min(CB, nR - jb);                    // columns of this round (wave-uniform)
+                            const uint2* rj = rp + jb;                               // column j: one broadcast LDS read for all rows
+                            // pass 1: pairs of the row that pass                      pk_compute.cpp:90-91
+                            uint32_t cnt = 0;
+#pragma unroll 8
+                            for (uint32_t j = 0; j < nc; ++j) {
+                                const float by = __uint_as_float(rj[j].y);
+                                const bool c = ay + by > eps;
+                                if constexpr (count_only) emitted += (uint32_t)__popcll(ballot64(c));
+                                else cnt += c ? 1u : 0u;
+                            }
+                            if constexpr (!count_only) {
+                                const bool has = cnt != 0;
+                                if (ballot64(has) == 0) continue;
+                                // every row reserves its run: {pairs before it in the bucket's open chunk, chunk id}
+                                unsigned long long got;
+                                asm volatile("" : "=v"(got));
+                                if (has) got = atomicAdd(&app.st[bk], (unsigned long long)cnt);
+                                uint32_t pre = (uint32_t)got, id = (uint32_t)(got >> 32);
+                                // the one run per bucket that reaches past the chunk's end: it and the runs behind it open a new chunk
+                                // (a bucket that gained more than a chunk's worth in this round crosses again in the new chunk: re-examined)
+                                for (;;) {
+                                    uint64_t X = ballot64(has && pre <= CH && pre + cnt > CH);
+                                    if (X == 0) break;
+                                    do {
+                                        const int ls = __ffsll((long long)X) - 1;
+                                        const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bk, ls);
+                                        const uint32_t xv = (uint32_t)__builtin_amdgcn_readlane((int)pre, ls);
+                                        const uint32_t xid = (uint32_t)__builtin_amdgcn_readlane((int)id, ls);
+                                        const uint32_t nid = app.roll_at(bb, xv);
+                                        const bool sel = has && bk == bb && id == xid && pre >= xv;       // (id: runs left behind in an earlier chunk stay)
+                                        id = sel ? nid : id;
+                                        pre = sel ? pre - xv : pre;
+                                        X &= X - 1ull;
+                                    } while (X);
+                                }
+                                unsigned long long run = reinterpret_cast<unsigned long long>(p.pool) + (((unsigned long long)id * CH + pre) << 3);
+                                // pass 2: the same columns again; the passing lanes store to their run
+                                if (p.flags & 2u) continue;                          // diagnostics: no second pass
+                                // (eight columns' reads are issued together: one LDS round trip per eight columns, not per column)
+                                auto emit8 = [&](auto FULLC, uint32_t j0) {
+                                    constexpr bool FULL = decltype(FULLC)::value;
+                                    uint2 b[8];
+#pragma unroll
+                                    for (uint32_t u = 0; u < 8; ++u) b[u] = rj[j0 + u];       // (past nc: entries of other lists, masked below)
+#pragma unroll
+                                    for (uint32_t u = 0; u < 8; ++u) {
+                                        float sj = ay + __uint_as_float(b[u].y);              // :90
+                                        if constexpr (!FULL) sj = j0 + u < nc ? sj : -__builtin_inff();
+                                        store_pair_if_gt(run, a.x + b[u].x, sj, eps);         // :91
+                                    }
+                                };
+                                uint32_t j0 = 0;
+                                for (; j0 + 8 <= nc; j0 += 8) emit8(std::true_type{}, j0);
+                                if (j0 < nc) emit8(std::false_type{}, j0);
+                            }
+                        }
+                    }
+                } else
                 // ---- final join: a block of <= 64 entries of R in registers, floor(64 / width) rows of L per step,
                 //      two steps per trip where two remain (their LDS round trips overlap) -----------------------------
                 for (uint32_t jb = 0; jb < nR; jb += 64) {
