@@ -234,6 +234,9 @@ def main():
         eng.set_option("variant", args.variant)
     if os.environ.get("IPKGPU_VARIANT"):
         eng.set_option("variant", int(os.environ["IPKGPU_VARIANT"]))   # diagnostics only
+    for knob in ("wg_chunks2", "rounds"):                     # tuning experiments only
+        if os.environ.get("IPKGPU_" + knob.upper()):
+            eng.set_option("debug_" + knob, int(os.environ["IPKGPU_" + knob.upper()]))
     if os.environ.get("IPKGPU_DEBUG_FLAGS"):
         eng.set_option("debug_flags", int(os.environ["IPKGPU_DEBUG_FLAGS"]))
 

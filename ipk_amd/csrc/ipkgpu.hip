@@ -66,6 +66,8 @@ struct ipkgpu_ctx {
     int64_t workspace_bytes = 0;
     int64_t opt_variant = 0;
     int64_t opt_flags = 0;
+    int64_t opt_wg_chunks2 = 0;       // tuning knob: overrides IPK_WG_CHUNKS2 (0 = built-in), opt_rounds: IPK_ROUNDS
+    int64_t opt_rounds = 0;
     int64_t opt_pool_chunks = 0;      // test knob: size of the FIRST pair-pool attempt (forces the grow-and-redo path)
     DevBuf table, best, ovfq, counts, offsets, goff, idx, branch, scan_sums, scan_boff, tmp_a, tmp_b, tmp_c;
     DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
@@ -312,6 +314,8 @@ int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "variant")) { ctx->opt_variant = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_flags")) { ctx->opt_flags = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_pool_chunks")) { ctx->opt_pool_chunks = value; return IPKGPU_OK; }
+    if (!strcmp(name, "debug_wg_chunks2")) { ctx->opt_wg_chunks2 = value; return IPKGPU_OK; }
+    if (!strcmp(name, "debug_rounds")) { ctx->opt_rounds = value; return IPKGPU_OK; }
     return fail(ctx, IPKGPU_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -1126,12 +1130,13 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
 #ifndef IPK_WG_CHUNKS2
 #define IPK_WG_CHUNKS2 2      // a wavefront should fill at least IPK_WG_CHUNKS2 / 2 chunks per bucket (4: +3.5 % at a 125-group share of cfg2)
 #endif
-    const uint64_t max_wg = std::max<uint64_t>(slots, expected_chunks * 2 / IPK_WG_CHUNKS2 / ((uint64_t)SNW * NBK * SUB));
+    const uint64_t wg_chunks2 = ctx->opt_wg_chunks2 > 0 ? (uint64_t)ctx->opt_wg_chunks2 : (uint64_t)IPK_WG_CHUNKS2;
+    const uint64_t max_wg = std::max<uint64_t>(slots, expected_chunks * 2 / wg_chunks2 / ((uint64_t)SNW * NBK * SUB));
     // whole rounds of resident workgroups: a partial last round leaves CUs idle for a full workgroup's run time
 #ifndef IPK_ROUNDS
 #define IPK_ROUNDS 8
 #endif
-    const uint64_t rounds = std::max<uint64_t>(1, std::min<uint64_t>(IPK_ROUNDS, max_wg / slots));
+    const uint64_t rounds = std::max<uint64_t>(1, std::min<uint64_t>(ctx->opt_rounds > 0 ? (uint64_t)ctx->opt_rounds : (uint64_t)IPK_ROUNDS, max_wg / slots));
     uint64_t S64 = std::max<uint64_t>(1, (slots * rounds) / gb);
     uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(S64, s_tiles_per_mat));
     const uint32_t n_wg = gb * S;

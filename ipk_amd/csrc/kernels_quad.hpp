@@ -525,16 +525,31 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                             const uint2* rj = rp + jb;                               // column j: one broadcast LDS read for all rows
                             // pass 1: pairs of the row that pass                      pk_compute.cpp:90-91
                             uint32_t cnt = 0;
-#pragma unroll 8
-                            for (uint32_t j = 0; j < nc; ++j) {
-                                const float by = __uint_as_float(rj[j].y);
-                                const bool c = ay + by > eps;
-                                if constexpr (count_only) emitted += (uint32_t)__popcll(ballot64(c));
-                                else cnt += c ? 1u : 0u;
+                            if constexpr (count_only) {
+                                for (uint32_t j = 0; j < nc; ++j) emitted += (uint32_t)__popcll(ballot64(ay + __uint_as_float(rj[j].y) > eps));
+                            } else {
+                                // (compare + add-with-carry per column, spelled out: left to itself the compiler pairs the columns and
+                                //  spends a v_cndmask per column on it)
+                                auto count8 = [&](auto NC, uint32_t j0, uint32_t& n, float e) {   // (n, e: an asm operand must not be a capture)
+                                    constexpr uint32_t N = decltype(NC)::value;
+                                    float by[N];
+#pragma unroll
+                                    for (uint32_t u = 0; u < N; ++u) by[u] = __uint_as_float(rj[j0 + u].y);
+#pragma unroll
+                                    for (uint32_t u = 0; u < N; ++u) {
+                                        const float sj = ay + by[u];                  // :90
+                                        asm("v_cmp_lt_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(n) : "v"(sj), "s"(e) : "vcc");   // :91
+                                    }
+                                };
+                                uint32_t j0 = 0;
+                                for (; j0 + 8 <= nc; j0 += 8) count8(std::integral_constant<uint32_t, 8>{}, j0, cnt, eps);
+                                if (j0 + 4 <= nc) { count8(std::integral_constant<uint32_t, 4>{}, j0, cnt, eps); j0 += 4; }
+                                for (; j0 < nc; ++j0) count8(std::integral_constant<uint32_t, 1>{}, j0, cnt, eps);
                             }
                             if constexpr (!count_only) {
                                 const bool has = cnt != 0;
                                 if (ballot64(has) == 0) continue;
+                                if (p.flags & 16u) { emitted += cnt; continue; }      // diagnostics: first pass only
                                 // every row reserves its run: {pairs before it in the bucket's open chunk, chunk id}
                                 unsigned long long got;
                                 asm volatile("" : "=v"(got));
@@ -561,21 +576,19 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                                 // pass 2: the same columns again; the passing lanes store to their run
                                 if (p.flags & 2u) continue;                          // diagnostics: no second pass
                                 // (eight columns' reads are issued together: one LDS round trip per eight columns, not per column)
-                                auto emit8 = [&](auto FULLC, uint32_t j0) {
-                                    constexpr bool FULL = decltype(FULLC)::value;
-                                    uint2 b[8];
+                                auto emit8 = [&](auto NC, uint32_t j0) {
+                                    constexpr uint32_t N = decltype(NC)::value;
+                                    uint2 b[N];
 #pragma unroll
-                                    for (uint32_t u = 0; u < 8; ++u) b[u] = rj[j0 + u];       // (past nc: entries of other lists, masked below)
+                                    for (uint32_t u = 0; u < N; ++u) b[u] = rj[j0 + u];
 #pragma unroll
-                                    for (uint32_t u = 0; u < 8; ++u) {
-                                        float sj = ay + __uint_as_float(b[u].y);              // :90
-                                        if constexpr (!FULL) sj = j0 + u < nc ? sj : -__builtin_inff();
-                                        store_pair_if_gt(run, a.x + b[u].x, sj, eps);         // :91
-                                    }
+                                    for (uint32_t u = 0; u < N; ++u)
+                                        store_pair_if_gt(run, a.x + b[u].x, ay + __uint_as_float(b[u].y), eps);   // :90, :91
                                 };
                                 uint32_t j0 = 0;
-                                for (; j0 + 8 <= nc; j0 += 8) emit8(std::true_type{}, j0);
-                                if (j0 < nc) emit8(std::false_type{}, j0);
+                                for (; j0 + 8 <= nc; j0 += 8) emit8(std::integral_constant<uint32_t, 8>{}, j0);
+                                if (j0 + 4 <= nc) { emit8(std::integral_constant<uint32_t, 4>{}, j0); j0 += 4; }
+                                for (; j0 < nc; ++j0) emit8(std::integral_constant<uint32_t, 1>{}, j0);
                             }
                         }
                     }
