@@ -90,6 +90,10 @@ struct ipkgpu_ctx {
     std::unordered_map<void*, size_t> live_blocks;
     size_t cached_bytes = 0, cache_limit = 0;
     void* small = nullptr;            // emitted (u64) @0, ovf_count (u32) @16
+    // pinned staging of the small per-batch index uploads (matrix lists, group -> matrices CSR): copied from without a wait;
+    // up_done is recorded behind the last copy and waited for only before the staging is written again
+    void* h_up = nullptr; size_t h_up_cap = 0; hipEvent_t up_done = nullptr; bool up_pending = false;
+    unsigned long long emitted_host = 0; bool emitted_fetched = false;   // the batch's scored-k-mer count, read back with the batch's last wait
     double t_write_total = 0, t_write_device = 0, t_write_file = 0;   // last ipkgpu_db_write
     int num_cu = 256;
 };
@@ -178,6 +182,27 @@ static int ensure(ipkgpu_ctx* ctx, DevBuf& b, size_t need)
 
 
 // ---- caching device allocator for result buffers ---------------------------------------------------
+// Pinned upload staging of `bytes`: waits for the copies still reading the previous contents, grows if needed.
+static int upload_stage(ipkgpu_ctx* ctx, size_t bytes, void** out)
+{
+    if (ctx->up_pending) { HIP_TRY(ctx, hipEventSynchronize(ctx->up_done)); ctx->up_pending = false; }
+    if (!ctx->up_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->up_done, hipEventDisableTiming));
+    if (bytes > ctx->h_up_cap) {
+        if (ctx->h_up) { (void)hipHostFree(ctx->h_up); ctx->h_up = nullptr; ctx->h_up_cap = 0; }
+        const size_t cap = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+        HIP_TRY(ctx, hipHostMalloc(&ctx->h_up, cap, hipHostMallocDefault));
+        ctx->h_up_cap = cap;
+    }
+    *out = ctx->h_up;
+    return IPKGPU_OK;
+}
+static int upload_staged(ipkgpu_ctx* ctx)       // behind the last copy out of the staging
+{
+    HIP_TRY(ctx, hipEventRecord(ctx->up_done, ctx->stream));
+    ctx->up_pending = true;
+    return IPKGPU_OK;
+}
+
 static hipError_t ctx_alloc(ipkgpu_ctx* ctx, void** out, size_t bytes)
 {
     bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
@@ -299,6 +324,8 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
     ipkgpu_comm_release(ctx);
     if (ctx->small) (void)hipFree(ctx->small);
+    if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+    if (ctx->up_done) (void)hipEventDestroy(ctx->up_done);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -993,18 +1020,39 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
                      std::vector<uint32_t>& idx_host)
 {
     const uint32_t n_mats = pl.n_mats;
-    idx_host.resize((size_t)n_mats * 2);
+    (void)idx_host;
+    // host side of the batch's index arrays, in pinned staging: [mat_list | mat_slot] (2 x n_mats) and the group -> matrices
+    // CSR [gb + 1 offsets | matrices]; both uploads leave without a wait
     uint32_t nb = 0;
-    uint32_t* mat_list_h = idx_host.data();
-    uint32_t* mat_slot_h = idx_host.data() + n_mats;
+    for (uint32_t i = 0; i < n_mats; ++i) nb += (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb);
+    const size_t gm_words = (size_t)gb + 1 + nb;
+    void* stage = nullptr;
+    RC_TRY(upload_stage(ctx, ((size_t)n_mats * 2 + gm_words) * 4, &stage));
+    uint32_t* mat_list_h = reinterpret_cast<uint32_t*>(stage);
+    uint32_t* mat_slot_h = mat_list_h + n_mats;
+    uint32_t* gm = mat_slot_h + n_mats;
+    nb = 0;
     for (uint32_t i = 0; i < n_mats; ++i) {
         mat_slot_h[i] = 0;
         if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) { mat_list_h[nb++] = i; mat_slot_h[i] = pl.slot_of[i] - g0; }
     }
+    for (uint32_t i = nb; i < n_mats; ++i) mat_list_h[i] = 0;
+    // matrices of each group of the batch (CSR)
+    for (size_t i = 0; i < gm_words; ++i) gm[i] = 0;
+    for (uint32_t i = 0; i < n_mats; ++i)
+        if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) gm[pl.slot_of[i] - g0 + 1]++;
+    for (uint32_t g = 0; g < gb; ++g) gm[g + 1] += gm[g];
+    {
+        std::vector<uint32_t> cur(gm, gm + gb);
+        for (uint32_t i = 0; i < n_mats; ++i)
+            if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) gm[(size_t)gb + 1 + cur[pl.slot_of[i] - g0]++] = i;
+    }
     RC_TRY(ensure(ctx, ctx->idx, (size_t)n_mats * 8));
     RC_TRY(ensure(ctx, ctx->ovfq, (size_t)nb * pl.nwin * 8));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->idx.p, idx_host.data(), (size_t)n_mats * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // idx_host is pageable and reused by the next batch
+    RC_TRY(ensure(ctx, ctx->gm, gm_words * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->idx.p, mat_list_h, (size_t)n_mats * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->gm.p, gm, gm_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    RC_TRY(upload_staged(ctx));
 
     ScoreParams p;
     p.logp = logp_dev;
@@ -1056,19 +1104,6 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     }
 
     // ---- stream variant: pass 1 (append pairs) -> chunk index -> pass 2 (LDS reduce) -> big-list windows
-    // matrices of each group of the batch (CSR)
-    std::vector<uint32_t> gm((size_t)gb + 1 + nb, 0);
-    for (uint32_t i = 0; i < n_mats; ++i)
-        if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) gm[pl.slot_of[i] - g0 + 1]++;
-    for (uint32_t g = 0; g < gb; ++g) gm[g + 1] += gm[g];
-    {
-        std::vector<uint32_t> cur(gm.begin(), gm.begin() + gb);
-        for (uint32_t i = 0; i < n_mats; ++i)
-            if (pl.slot_of[i] >= g0 && pl.slot_of[i] < g0 + gb) gm[(size_t)gb + 1 + cur[pl.slot_of[i] - g0]++] = i;
-    }
-    RC_TRY(ensure(ctx, ctx->gm, gm.size() * 4));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->gm.p, gm.data(), gm.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // occupancy bits of the tables: written by the LDS reduce pass, kept current by the big-list kernel, read by km_count
     ctx->mask_words = 2 * ((pl.table_size + 63) / 64);
     RC_TRY(ensure(ctx, ctx->mask, (size_t)gb * ctx->mask_words * 4));
@@ -1257,7 +1292,9 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         RC_TRY(dispatch_stream_pass2(ctx, pl.sigma, pl.k, (uint32_t)n_gb, pl.table_size, ctx->table.as<uint32_t>()));
         const int ev_d = sw.mark();
         if (n_ovf > 0 && !ovf_in_pool) RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
+        HIP_TRY(ctx, hipMemcpyAsync(&ctx->emitted_host, p.emitted, 8, hipMemcpyDeviceToHost, ctx->stream));   // (one wait for both)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->emitted_fetched = true;
         ctx->mask_valid = true;
         ctx->acc_main_ms += sw.ms(ev_a, ev_b);
         ctx->acc_reduce_ms += sw.ms(ev_c, ev_d);
@@ -1271,10 +1308,13 @@ int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t
                 std::vector<uint32_t>& idx_host, uint64_t* emitted_acc)
 {
     HIP_TRY(ctx, hipMemsetAsync(ctx->small, 0, 8, ctx->stream));            // per-batch scored-k-mer counter
+    ctx->emitted_fetched = false;
     RC_TRY(score_batch_impl(ctx, pl, logp_dev, g0, gb, idx_host));
-    unsigned long long e = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&e, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long e = ctx->emitted_host;
+    if (!ctx->emitted_fetched) {
+        HIP_TRY(ctx, hipMemcpyAsync(&e, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     *emitted_acc += e;
     // calibration of the next call's pair pool and workgroup count: PAIRS per window (not chunks -- chunk
     // counts include every wave's open chunks and would feed back into the workgroup count)
@@ -1284,19 +1324,21 @@ int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t
     return IPKGPU_OK;
 }
 
-// out[0..n] = base + exclusive scan of in[0..n)   (u32 -> u64)
+// out[0..n] = exclusive scan of in[0..n)   (u32 -> u64; out[n] = the total): one single-pass device scan (rocPRIM, decoupled
+// look-back) over n + 1 items, the last one a zero -- two launches where the three-kernel scan (block sums, one workgroup over
+// the sums, apply) cost 27 us per call at a million keys, four times per scoring call.
+struct ScanU32In {
+    const uint32_t* in; uint64_t n;
+    __host__ __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)in[i] : 0ull; }
+};
 int scan_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out)
 {
     if (n == 0) { HIP_TRY(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return IPKGPU_OK; }
-    const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (nb > 0x7fffffffull) return fail(ctx, IPKGPU_ERR_INVALID, "scan too large");
-    RC_TRY(ensure(ctx, ctx->scan_sums, nb * 4));
-    RC_TRY(ensure(ctx, ctx->scan_boff, (nb + 1) * 8));
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((uint32_t)nb), dim3(256), 0, ctx->stream, in, n, ctx->scan_sums.as<uint32_t>());
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->scan_sums.as<uint32_t>(), nb, (uint64_t)0,
-                       ctx->scan_boff.as<uint64_t>());
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((uint32_t)nb), dim3(256), 0, ctx->stream, in, n, ctx->scan_boff.as<uint64_t>(), out);
-    HIP_TRY(ctx, hipGetLastError());
+    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), ScanU32In{in, n});
+    size_t bytes = 0;
+    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), ctx->stream));
+    RC_TRY(ensure(ctx, ctx->scan_sums, bytes));
+    HIP_TRY(ctx, rocprim::exclusive_scan(ctx->scan_sums.p, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), ctx->stream));
     return IPKGPU_OK;
 }
 

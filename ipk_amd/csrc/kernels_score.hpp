@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict
                                                          float* __restrict__ best)
 {
     constexpr int CH = 4096;
-    __shared__ float cm[CH];
+    __shared__ __align__(16) float cm[CH];
     __shared__ float carry;
     const uint32_t mat = blockIdx.x;
     const float* m = logp + (size_t)mat * sites * SIGMA;
@@ -45,9 +45,24 @@ __global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict
         }
         __syncthreads();
         if (threadIdx.x == 0) {
+            // The chain of float additions IS the algorithm (a scan would round differently): what can be cut is everything
+            // around it -- sixteen maxima per LDS round trip (four 16-byte reads issued together, the next sixteen already in
+            // flight while these are added), the sums written back the same way.
             float acc = carry;
-#pragma unroll 8
-            for (uint32_t j = 0; j < n; ++j) { acc += cm[j]; cm[j] = acc; }
+            float4* c4 = reinterpret_cast<float4*>(cm);
+            const uint32_t n16 = n / 16;
+            float4 nx0, nx1, nx2, nx3;
+            if (n16) { nx0 = c4[0]; nx1 = c4[1]; nx2 = c4[2]; nx3 = c4[3]; }
+            for (uint32_t q = 0; q < n16; ++q) {
+                float4 v0 = nx0, v1 = nx1, v2 = nx2, v3 = nx3;
+                if (q + 1 < n16) { nx0 = c4[4 * q + 4]; nx1 = c4[4 * q + 5]; nx2 = c4[4 * q + 6]; nx3 = c4[4 * q + 7]; }
+                acc += v0.x; v0.x = acc; acc += v0.y; v0.y = acc; acc += v0.z; v0.z = acc; acc += v0.w; v0.w = acc;
+                acc += v1.x; v1.x = acc; acc += v1.y; v1.y = acc; acc += v1.z; v1.z = acc; acc += v1.w; v1.w = acc;
+                acc += v2.x; v2.x = acc; acc += v2.y; v2.y = acc; acc += v2.z; v2.z = acc; acc += v2.w; v2.w = acc;
+                acc += v3.x; v3.x = acc; acc += v3.y; v3.y = acc; acc += v3.z; v3.z = acc; acc += v3.w; v3.w = acc;
+                c4[4 * q] = v0; c4[4 * q + 1] = v1; c4[4 * q + 2] = v2; c4[4 * q + 3] = v3;
+            }
+            for (uint32_t j = n16 * 16; j < n; ++j) { acc += cm[j]; cm[j] = acc; }
             carry = acc;
         }
         __syncthreads();
