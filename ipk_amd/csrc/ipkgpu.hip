@@ -68,6 +68,7 @@ struct ipkgpu_ctx {
     int64_t opt_flags = 0;
     int64_t opt_wg_chunks2 = 0;       // tuning knob: overrides IPK_WG_CHUNKS2 (0 = built-in), opt_rounds: IPK_ROUNDS
     int64_t opt_rounds = 0;
+    int64_t opt_pool_limit = 0;       // test knob: bytes the pair pool may take (0 = what the device has free)
     int64_t opt_pool_chunks = 0;      // test knob: size of the FIRST pair-pool attempt (forces the grow-and-redo path)
     DevBuf table, best, ovfq, counts, offsets, goff, idx, branch, scan_sums, scan_boff, tmp_a, tmp_b, tmp_c;
     DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
@@ -341,6 +342,7 @@ int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "variant")) { ctx->opt_variant = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_flags")) { ctx->opt_flags = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_pool_chunks")) { ctx->opt_pool_chunks = value; return IPKGPU_OK; }
+    if (!strcmp(name, "debug_pool_limit_bytes")) { ctx->opt_pool_limit = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_wg_chunks2")) { ctx->opt_wg_chunks2 = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_rounds")) { ctx->opt_rounds = value; return IPKGPU_OK; }
     return fail(ctx, IPKGPU_ERR_INVALID, "unknown option '%s'", name);
@@ -867,6 +869,10 @@ int dispatch_score(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const ScoreParam
 // ---- the scoring pass shared by every output form ---------------------------------------------------
 namespace {
 
+// internal status of a scoring batch: its pair pool does not fit device memory -- the caller halves the batch and scores
+// it again (the reference's answer to "does not fit" is its on-disk mode, db_builder.cpp:673-681; here: smaller batches)
+constexpr int IPKGPU_RETRY_SMALLER = 100;
+
 struct Plan {
     uint32_t n_mats = 0, sites = 0, sigma = 0, k = 0;
     float eps = 0;
@@ -900,7 +906,17 @@ int make_plan(ipkgpu_ctx* ctx, const void* logp, uint32_t n_mats, uint32_t sites
     pl.n_groups = (uint32_t)pl.group_ids.size();
     pl.table_size = ipow(sigma, (int)k);
     pl.chunks_per_group = (uint32_t)((pl.table_size + CHUNK - 1) / CHUNK);
-    pl.gpb = std::max<uint64_t>(1, (uint64_t)ctx->workspace_bytes / (pl.table_size * 4));
+    // groups per batch: what a group keeps resident at once -- its score table and its share of the pair pool (the scored
+    // phylo-k-mers of its windows, 8 bytes each, at the rate calibrated by the context's previous call or its pre-pass; a
+    // guess of 256 per window before that) -- against workspace_bytes.  An underestimate is caught later: a batch whose pool
+    // does not fit is halved and scored again (IPKGPU_RETRY_SMALLER).
+    pl.nwin = sites - k + 1;
+    {
+        const double ppw = ctx->pairs_per_window > 0 ? ctx->pairs_per_window : 256.0;
+        const double pool_per_group = (double)n_mats / (double)pl.n_groups * (double)pl.nwin * ppw * 8.0 * 1.25;
+        const double per_group = (double)pl.table_size * 4.0 + pool_per_group;
+        pl.gpb = std::max<uint64_t>(1, (uint64_t)((double)ctx->workspace_bytes / per_group));
+    }
     pl.gpb = std::min<uint64_t>(pl.gpb, pl.n_groups);
     while (pl.gpb > 1 && pl.gpb * pl.chunks_per_group > 0x7fffffffull) pl.gpb /= 2;
     pl.nwin = sites - k + 1;
@@ -970,9 +986,11 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        if (total * 8 > ctx->pool.cap && total * 8 > free_b + ctx->pool.cap)
-            return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool (%llu pairs) does not fit device memory (lower workspace_bytes to score fewer groups per batch)",
-                        (unsigned long long)total);
+        const bool over_limit = ctx->opt_pool_limit > 0 && total * 8 > (uint64_t)ctx->opt_pool_limit;
+        if (over_limit || (total * 8 > ctx->pool.cap && total * 8 > free_b + ctx->pool.cap)) {
+            if (gb > 1) return IPKGPU_RETRY_SMALLER;
+            return fail(ctx, IPKGPU_ERR_NOMEM, "the pair pool of ONE branch group (%llu pairs) does not fit device memory", (unsigned long long)total);
+        }
     }
     RC_TRY(ensure(ctx, ctx->pool, std::max<uint64_t>(total, 1) * 8 + 256));     // (+256: km_write_c_kernel reads up to 32 values from a row's start)
     {
@@ -1180,7 +1198,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
 
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    const uint64_t max_chunks = std::min<uint64_t>(0xFFFFFFF0ull, (uint64_t)(free_b + ctx->pool.cap + ctx->desc.cap) * 9 / 10 / (CH * 8 + 8));
+    uint64_t max_chunks = std::min<uint64_t>(0xFFFFFFF0ull, (uint64_t)(free_b + ctx->pool.cap + ctx->desc.cap) * 9 / 10 / (CH * 8 + 8));
+    if (ctx->opt_pool_limit > 0) max_chunks = std::min<uint64_t>(max_chunks, (uint64_t)ctx->opt_pool_limit / (CH * 8 + 8));
     // pool size: pairs expected (calibrated by the previous call, +25 %) plus every wave's open chunks and id batches.
     // An existing pool is kept as long as it covers the expectation without the margin -- regrowing a multi-GB
     // buffer costs hundreds of ms, and an underestimate is caught by the redo path anyway.
@@ -1199,7 +1218,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         uint64_t cap = std::min<uint64_t>(want, max_chunks);
         const bool forced = attempt == 0 && ctx->opt_pool_chunks > 0;
         if (forced) cap = (uint64_t)ctx->opt_pool_chunks;
-        else if (cap < n_waves * NBK * SUB) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool does not fit device memory (lower workspace_bytes)");
+        else if (cap < n_waves * NBK * SUB) {
+            if (gb > 1) return IPKGPU_RETRY_SMALLER;
+            return fail(ctx, IPKGPU_ERR_NOMEM, "the pair pool of ONE branch group does not fit device memory");
+        }
         RC_TRY(ensure(ctx, ctx->pool, (cap + 1) * CH * 8));
         RC_TRY(ensure(ctx, ctx->desc, cap * 8));
         if (!forced) cap = std::min<uint64_t>(ctx->pool.cap / (CH * 8) - 1, ctx->desc.cap / 8);
@@ -1263,7 +1285,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
         if (h[1] != 0) {                    // pool exhausted: h[0] chunks were asked for
-            if (cap >= max_chunks) return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool exhausted at the device-memory limit (lower workspace_bytes to score fewer groups per batch)");
+            if (cap >= max_chunks) {
+                if (gb > 1) return IPKGPU_RETRY_SMALLER;
+                return fail(ctx, IPKGPU_ERR_NOMEM, "the pair pool of ONE branch group is exhausted at the device-memory limit");
+            }
             // (h[0] = ids drawn is no measure of the need: an exhausted pool is asked again at every append)
             want = std::max<uint64_t>(cap * 2, want);
             continue;
@@ -1378,10 +1403,13 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
     std::vector<std::pair<int, int>> ev_score, ev_compact;
     std::vector<uint32_t> idx_host;
     uint64_t total_entries = 0;
-    for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)pl.gpb) {
-        const uint32_t gb = std::min<uint32_t>((uint32_t)pl.gpb, n_groups - g0);
+    uint32_t gpb_now = (uint32_t)pl.gpb, gb = 0;
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += gb) {
+        gb = std::min<uint32_t>(gpb_now, n_groups - g0);
         const int s0 = sw.mark();
-        RC_TRY(score_batch(ctx, pl, logp_dev, g0, gb, idx_host, &res->emitted));
+        const int rcb = score_batch(ctx, pl, logp_dev, g0, gb, idx_host, &res->emitted);
+        if (rcb == IPKGPU_RETRY_SMALLER) { gpb_now = std::max<uint32_t>(1, gb / 2); gb = 0; continue; }   // the batch again, half as many groups
+        if (rcb) return rcb;
         const int s1 = sw.mark();
         ev_score.push_back({s0, s1});
         res->score_launches += 1;
@@ -1787,10 +1815,13 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     struct BGuard { decltype(free_batches)& f; ~BGuard() { f(); } } bguard{free_batches};
 
     const uint64_t n_slots_all = (uint64_t)P * slots;
-    for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)pl.gpb) {
-        const uint32_t gb = std::min<uint32_t>((uint32_t)pl.gpb, n_groups - g0);
+    uint32_t gpb_now = (uint32_t)pl.gpb, gb = 0;
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += gb) {
+        gb = std::min<uint32_t>(gpb_now, n_groups - g0);
         const int s0 = sw.mark();
-        RC_TRY(score_batch(ctx, pl, logp_dev, g0, gb, idx_host, &parts->emitted));
+        const int rcb = score_batch(ctx, pl, logp_dev, g0, gb, idx_host, &parts->emitted);
+        if (rcb == IPKGPU_RETRY_SMALLER) { gpb_now = std::max<uint32_t>(1, gb / 2); gb = 0; continue; }   // the batch again, half as many groups
+        if (rcb) return rcb;
         const int s1 = sw.mark();
         ev_score.push_back({s0, s1});
         parts->score_launches += 1;

@@ -396,3 +396,51 @@ def test_exec_assert_build():
                          env=dict(os.environ, IPKGPU_LIB=lib, PYTHONPATH=root))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert "EXEC_VIOLATIONS 0" in out.stdout
+
+
+@pytest.mark.parametrize("sigma,k,sites,alpha,limit", [(4, 10, 300, 0.05, 20 << 20), (20, 6, 40, 0.03, 4 << 20)],
+                         ids=["dna_k10_chunked_pool", "aa_k6_exact_partition"])
+def test_pool_that_does_not_fit_means_smaller_batches(sigma, k, sites, alpha, limit):
+    """The pair pool of a batch does not fit device memory (here: an artificial limit): the engine halves the batch and
+    scores it again instead of failing -- the reference's valve for "does not fit" is its on-disk mode
+    (db_builder.cpp:673-681); results are the oracle's either way, group order included."""
+    n_groups = 8
+    mats = synth_matrices(2 * n_groups, sites, sigma, alpha, 991)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 30, 2)
+    eps = co.log_threshold(1.5, sigma, k)
+    eng = ipk_amd.Engine(0)
+    try:
+        one = eng.score_groups(mats, groups, k, eps)
+        launches_free = one.time_ms(4)                                  # IPKGPU_T_SCORE_LAUNCHES
+        one.free()
+        eng.set_option("debug_pool_limit_bytes", limit)
+        res = eng.score_groups(mats, groups, k, eps)
+        assert res.time_ms(4) > launches_free, "the limit did not force smaller batches"
+        res.free()
+        check_against_oracle(eng, mats, groups, k, eps)
+        parts = eng.score_groups_keymajor(mats, groups, k, eps, n_owners=1)
+        db = eng.db_from_parts(parts, sigma, k)
+        full, emitted = _oracle_db(mats, groups, k, eps)
+        assert parts.emitted == emitted and parts.time_ms(4) > 1
+        keys, off = db.keys(), db.key_offsets()
+        br, sc = db.entries()
+        assert len(keys) == len(full)
+        bits = ipk_amd.bits_per_symbol(sigma)
+        for i in range(0, len(keys), max(1, len(keys) // 500)):          # a sample of the keys, every entry of each
+            e = full[int(keys[i])]
+            assert [int(b) for b in br[off[i]:off[i + 1]]] == [b for b, _ in e]
+            assert [int(x) for x in sc[off[i]:off[i + 1]].view(np.uint32)] == [x for _, x in e]
+        db.free(); parts.free()
+    finally:
+        eng.close()
+
+
+def _oracle_db(mats, groups, k, eps):
+    """key -> [(branch, score bits)] in group (first-seen) order, and the scored count: the oracle's explore_group per group."""
+    full, emitted = {}, 0
+    for gid in dict.fromkeys(np.asarray(groups).tolist()):
+        keys, scores, e = co.explore_group(mats[np.asarray(groups) == gid], k, eps)
+        emitted += e
+        for key, s in zip(keys.tolist(), scores.view(np.uint32).tolist()):
+            full.setdefault(key, []).append((gid, s))
+    return full, emitted
