@@ -391,6 +391,24 @@ def main():
                 out["e2e"] = json.loads(line[0][4:]) if line else {"error": (pr.stderr or pr.stdout)[-800:]}
             except Exception as exc:                              # e.g. no room for the file: the steady-state line stays valid
                 out["e2e"] = {"error": repr(exc)}
+            # the loader (raxmlng_reader, ar.cpp:144-270; inside the reference's stage-1 timer, outside `value` here -- SURVEY 8d:
+            # "reported separately"): a bounded sample of the config's .raxml.ancestralProbs, text -> log10 float32 matrices
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import loader_bench
+                n_sample = min(n_mats, 200)
+                lb = loader_bench.measure(n_sample, sites, sigma)
+                full_bytes = lb["file_bytes"] / n_sample * n_mats
+                allc = lb["read"][-1]
+                lb["sample"] = f"{n_sample} of {n_mats} nodes ({lb['file_bytes'] / 1e6:.0f} MB of text); full file {full_bytes / 1e9:.2f} GB"
+                lb["loader_s_est"] = full_bytes / (lb["open_index_GBps"] * 1e9) + full_bytes / (allc["text_GBps"] * 1e9)
+                lb["loader_s_est_note"] = f"index + read of the full file at the sample's rates, {allc['threads']} threads"
+                if isinstance(out.get("e2e"), dict):
+                    out["e2e"]["loader"] = lb
+                    out["e2e"]["loader_s"] = lb["loader_s_est"]
+            except Exception as exc:
+                if isinstance(out.get("e2e"), dict):
+                    out["e2e"]["loader"] = {"error": repr(exc)}
         # CPU baseline: the oracle (C restatement), 1 thread, bounded sample of the same workload
         n_cpu = args.cpu_groups
         if world == 1 and n_cpu != 0:

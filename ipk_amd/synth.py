@@ -42,3 +42,23 @@ CONFIGS = {
     "cfg5": dict(n_groups=1300, mats_per_group=2, sites=1400, sigma=4, k=10, omega=1.5, alpha=0.05, seed=44),
     "cfg4": dict(n_groups=250, mats_per_group=2, sites=3000, sigma=20, k=6, omega=1.5, alpha=0.03, seed=43),
 }
+
+
+def write_ancestral_probs(path, n_nodes, sites, sigma, seed=7, pool=4093):
+    """A synthetic RAxML-ng `.raxml.ancestralProbs` of the benchmark's shape (header + n_nodes x sites rows
+    `Node<i> TAB site TAB state TAB p_1 .. p_sigma`, 9 decimals as RAxML-ng writes with --precision 9, ar.cpp:670): what the
+    loader (ipkgpu_ar_*) is timed on.  Rows are drawn from a pool of `pool` distinct probability vectors -- the text has the
+    size and shape of a real file, which is all the parser's speed depends on.  Returns the file size in bytes."""
+    rng = np.random.default_rng(seed)
+    states = "ACGT" if sigma == 4 else "ARNDCQEGHILKMFPSTWYV"
+    p = rng.dirichlet(np.full(sigma, 0.1), size=pool)
+    rows = [states[int(np.argmax(v))] + "\t" + "\t".join("%.9f" % x for x in v) + "\n" for v in p]
+    site_txt = [str(s + 1) + "\t" for s in range(sites)]
+    with open(path, "w") as fh:
+        fh.write("Node\tSite\tState\t" + "\t".join("p_" + c for c in states) + "\n")
+        for i in range(n_nodes):
+            lab = f"Node{i + 1}\t"
+            o = (i * 7919) % pool
+            fh.write("".join(lab + site_txt[s] + rows[(o + s) % pool] for s in range(sites)))
+    import os
+    return os.path.getsize(path)

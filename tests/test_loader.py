@@ -77,3 +77,31 @@ def test_loader_feeds_the_oracle_pipeline(tmp_path):
     mats = AncestralProbs(path, 4).read()
     keys, scores, emitted = co.explore_group(mats, 6, co.log_threshold(1.5, 4, 6))
     assert emitted > 0 and len(keys) > 0 and np.all(scores <= 0)
+
+
+def test_index_is_stitched_across_thread_ranges(tmp_path):
+    """A file large enough for the index scan to be split over several threads (8 MB of text per range): labels, their
+    order and every block boundary must come out as from one left-to-right pass -- including a node whose block spans a
+    cut and a label that re-appears later in the file (the later block wins, ar.cpp:181 assigns into the map)."""
+    rng = np.random.default_rng(3)
+    rows = ["\t".join("%.9f" % v for v in rng.dirichlet(np.full(4, 0.1))) for _ in range(997)]
+    n_nodes, sites = 140, 2500
+    labels = [f"Node{i + 1}" for i in range(n_nodes)]
+    path = tmp_path / "big.raxml.ancestralProbs"
+    with open(path, "w") as fh:
+        fh.write("Node\tSite\tState\tp_A\tp_C\tp_G\tp_T\n")
+        for li, lab in enumerate(labels):
+            fh.write("".join(f"{lab}\t{s + 1}\tA\t{rows[(li * 31 + s * 7) % 997]}\n" for s in range(sites)))
+        fh.write("".join(f"Node3\t{s + 1}\tC\t{rows[(5 + s) % 997]}\n" for s in range(sites)))      # Node3 again: this block counts
+    assert path.stat().st_size > 20 << 20
+    ar = AncestralProbs(path, 4)
+    assert ar.labels == labels and ar.sites == sites
+    pick = ["Node1", "Node3", "Node70", "Node71", "Node140"]
+    mats = ar.read(pick, n_threads=4)
+    for i, lab in enumerate(pick):
+        li = labels.index(lab)
+        src = [rows[(5 + s) % 997] if lab == "Node3" else rows[(li * 31 + s * 7) % 997] for s in range(sites)]
+        ref = np.array([[ar_oracle.parse_float(v) for v in r.split("\t")] for r in src], dtype=np.float32)
+        from oracle import ipk_oracle as co
+        assert np.array_equal(mats[i].view(np.uint32), co.log10f(ref).view(np.uint32)), lab
+    ar.close()
