@@ -366,6 +366,15 @@ int ipkgpu_db_write_host(const ipkgpu_db_header* header, uint64_t n_keys, const 
                          const uint32_t* entries, const float* filter_values, const uint32_t* order, const char* path,
                          uint64_t* bytes_written);
 const char* ipkgpu_db_write_last_error(void);
+/* The database file of a multi-GPU build -- the role of merge_stage2 (db_builder.cpp:392-458: batch files opened together,
+ * a priority queue on the filter value hands out the k-mer to append next).  Every rank writes ITS shard (the k-mers it owns,
+ * filter values computed, in its filter order) as a database file of its own with ipkgpu_db_write / ipkgpu_db_write_host
+ * (any header: only the totals are read back); one rank then merges the P shard files by (filter value, key) into `path`
+ * under header `h`, streaming through bounded buffers: resident memory does not depend on the number of entries, and the
+ * result equals, byte for byte, the file one GPU writes for the same input.  Host code, no GPU needed. */
+int ipkgpu_db_merge_files(const ipkgpu_db_header* h, const char* const* shard_paths, uint32_t n_shards, const char* path,
+                          uint64_t* total_kmers, uint64_t* total_entries, uint64_t* bytes_written);
+const char* ipkgpu_db_merge_last_error(void);
 /* seconds of the last ipkgpu_db_write of this context: 0 = total, 1 = device packing + copies (waited for), 2 = file writes */
 double ipkgpu_db_write_time_s(const ipkgpu_ctx* ctx, int which);
 

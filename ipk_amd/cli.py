@@ -168,22 +168,29 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
         db.filter_mif0(eng, n_nodes, ipk_amd.score_threshold(omega, sigma, k))
     t_filter = time.time() - t0
     t0 = time.time()
-    if world == 1 and filter_ == "mif0":
-        # one GPU: records packed on the device in filter order and streamed to the file (ipkgpu_db_write)
-        dbfile.write_db_device(eng, db, output, seq_name, tree_index, newick, k, omega)
-        totals = (db.num_keys, db.num_entries)
+    if filter_ == "mif0":
+        # records packed on the device in filter order and streamed to the file (ipkgpu_db_write): the database itself on one
+        # GPU, this rank's shard on several (a shard's header carries only its totals)
+        def write_shard(file):
+            if world == 1:
+                dbfile.write_db_device(eng, db, file, seq_name, tree_index, newick, k, omega)
+            else:
+                dbfile.write_db_device(eng, db, file, seq_name, [], "", k, omega)
     else:
-        if filter_ == "mif0":
-            fv, order = db.filter_values().copy(), db.filter_order().copy()
-        else:
-            # random_filter (filter.cpp:122-145) draws uniform(0, 1) from std::default_random_engine(42) in the hash map's
-            # iteration order, which no other build reproduces; here: one fixed draw per k-mer CODE, so the file does not
-            # depend on how the k-mers are sharded
-            fv = (dbfile.splitmix_unit(db.keys()) if db.num_keys else np.zeros(0)).astype(np.float32)
-            order = np.argsort(dbfile.filter_sort_code(fv, db.keys()), kind="stable")
+        # random_filter (filter.cpp:122-145) draws uniform(0, 1) from std::default_random_engine(42) in the hash map's
+        # iteration order, which no other build reproduces; here: one fixed draw per k-mer CODE, so the file does not
+        # depend on how the k-mers are sharded
+        fv = (dbfile.splitmix_unit(db.keys()) if db.num_keys else np.zeros(0)).astype(np.float32)
+        order = np.argsort(dbfile.filter_sort_code(fv, db.keys()), kind="stable")
         br, sc = db.entries()
-        totals = distributed.write_db_file(output, seq_name, tree_index, newick, k, omega, db.keys(), db.key_offsets(),
-                                           br, sc, fv, order, workdir, dist, world, rank)
+
+        def write_shard(file):
+            one = world == 1
+            dbfile.write_db(file, seq_name, tree_index if one else [], newick if one else "", k, omega, db.keys(), db.key_offsets(),
+                            br, sc, fv, order)
+    totals = distributed.write_db_file(output, seq_name, tree_index, newick, k, omega, write_shard, workdir, dist, world, rank)
+    if world == 1:
+        totals = (db.num_keys, db.num_entries)
     t_write = time.time() - t0
     emitted = parts.emitted
     if world > 1:

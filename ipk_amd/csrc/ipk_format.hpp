@@ -15,6 +15,7 @@
 //   k-mers    per k-mer in filter order: u32 key ; f32 filter_value ; u64 n ; n x { u32 branch ; f32 score }
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,6 +62,35 @@ inline std::vector<uint8_t> file_head(const char* sequence_type, uint64_t n_inde
     put_v<uint64_t>(o, total_kmers);
     put_v<uint64_t>(o, total_entries);
     return o;
+}
+
+// ---- reading back what file_head wrote (the shard files of a multi-GPU build are database files themselves) ----------------
+inline bool get(FILE* f, void* p, size_t n) { return n == 0 || fread(p, 1, n, f) == n; }
+template <class T> inline bool get_v(FILE* f, T& v) { return get(f, &v, sizeof v); }
+inline bool skip_string(FILE* f, uint64_t limit = (uint64_t)1 << 32)
+{
+    uint64_t n = 0;
+    return get_v(f, n) && n <= limit && fseek(f, (long)n, SEEK_CUR) == 0;
+}
+// Positions `f` at the first k-mer record; the header's totals come back.  false: not a file of this layout.
+inline bool read_head(FILE* f, uint64_t& total_kmers, uint64_t& total_entries)
+{
+    uint64_t n = 0;
+    char magic[22];
+    if (!get_v(f, n) || n != 22 || !get(f, magic, 22) || memcmp(magic, "serialization::archive", 22) != 0) return false;
+    uint16_t ver; uint8_t sz[4]; int32_t one;
+    if (!get_v(f, ver) || !get(f, sz, 4) || !get_v(f, one) || sz[0] != 4 || sz[1] != 8 || sz[2] != 4 || sz[3] != 8 || one != 1) return false;
+    uint64_t n_index = 0, kmer_size = 0; float omega = 0;
+    if (!skip_string(f) || !get_v(f, n_index) || n_index > ((uint64_t)1 << 32) || fseek(f, (long)(n_index * 16), SEEK_CUR) != 0) return false;
+    if (!skip_string(f) || !get_v(f, kmer_size) || !get_v(f, omega)) return false;
+    return get_v(f, total_kmers) && get_v(f, total_entries);
+}
+// the order of the k-mer records: ascending filter value (as an order-preserving integer code of the float), ties by
+// ascending key -- kernels_filter.hpp's sort key, db_builder.cpp:281-284 (`std::sort` over kmer_fv)
+inline uint64_t record_sort_key(uint32_t key, uint32_t fv_bits)
+{
+    const uint32_t code = (fv_bits & 0x80000000u) ? ~fv_bits : (fv_bits | 0x80000000u);
+    return ((uint64_t)code << 32) | key;
 }
 
 }  // namespace ipkfmt

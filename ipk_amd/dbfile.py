@@ -13,7 +13,8 @@ import numpy as np
 
 from .engine import IpkGpuError, load_library
 
-ABI_SYMBOLS = ["ipkgpu_db_write", "ipkgpu_db_write_host", "ipkgpu_db_write_last_error", "ipkgpu_db_write_time_s"]
+ABI_SYMBOLS = ["ipkgpu_db_write", "ipkgpu_db_write_host", "ipkgpu_db_write_last_error", "ipkgpu_db_write_time_s",
+               "ipkgpu_db_merge_files", "ipkgpu_db_merge_last_error"]
 _bound = False
 
 
@@ -36,6 +37,11 @@ def _lib():
         L.ipkgpu_db_write_last_error.argtypes = []
         L.ipkgpu_db_write_time_s.restype = C.c_double
         L.ipkgpu_db_write_time_s.argtypes = [C.c_void_p, C.c_int]
+        L.ipkgpu_db_merge_files.restype = C.c_int
+        L.ipkgpu_db_merge_files.argtypes = [C.POINTER(_Header), C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ipkgpu_db_merge_last_error.restype = C.c_char_p
+        L.ipkgpu_db_merge_last_error.argtypes = []
         _bound = True
     return L
 
@@ -149,9 +155,9 @@ def read_db(path, as_arrays=False):
 
 
 # ---- several GPUs: every rank owns the k-mers with code % P == rank ---------------------------------
-# Filter values are per k-mer, so each rank computes them on its own shard; the final file is the merge of
-# the P shards by filter value -- the role merge_stage2 plays for the reference's on-disk batches
-# (db_builder.cpp:392-458: batch files opened together, smallest filter value written next).
+# Filter values are per k-mer, so each rank computes them on its own shard and writes the shard, in its own filter order, as a
+# database file; the final file is the streaming merge of the P shard files by filter value (ipkgpu_db_merge_files) -- the
+# role merge_stage2 plays for the reference's on-disk batches (db_builder.cpp:392-458).
 
 def filter_sort_code(filter_values, keys):
     """The engine's filter order as one integer per k-mer: order-preserving code of the float32 filter value, ties by
@@ -170,24 +176,14 @@ def splitmix_unit(keys):
     return (x >> np.uint64(40)).astype(np.float64) / float(1 << 24)
 
 
-def write_shard(path, keys, key_offsets, branches, scores, filter_values):
-    """One rank's shard (ascending keys) with its filter values, as plain arrays for merge_shards."""
-    with open(path, "wb") as fh:
-        np.savez(fh, keys=np.asarray(keys, dtype=np.uint32), off=np.asarray(key_offsets, dtype=np.uint64),
-                 br=np.asarray(branches, dtype=np.uint32), sc=np.asarray(scores, dtype=np.float32).view(np.uint32),
-                 fv=np.asarray(filter_values, dtype=np.float32))
-
-
-def merge_shards(path, sequence_type, tree_index, newick, kmer_size, omega, shard_paths):
-    """Merges the ranks' shards by (filter value, key) into one database file, identical to the file a single
-    GPU writes for the same input.  Returns (total k-mers, total entries)."""
-    keys, lens, br, sc, fv = [], [], [], [], []
-    for sp in shard_paths:
-        z = np.load(sp)
-        keys.append(z["keys"]); lens.append(np.diff(z["off"].astype(np.int64))); br.append(z["br"]); sc.append(z["sc"]); fv.append(z["fv"])
-    keys = np.concatenate(keys); lens = np.concatenate(lens); fv = np.concatenate(fv)
-    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    order = np.argsort(filter_sort_code(fv, keys), kind="stable")
-    write_db(path, sequence_type, tree_index, newick, kmer_size, omega, keys, off, np.concatenate(br),
-             np.concatenate(sc).view(np.float32), fv, order)
-    return len(keys), int(off[-1])
+def merge_shard_files(path, sequence_type, tree_index, newick, kmer_size, omega, shard_paths):
+    """ipkgpu_db_merge_files: streaming P-way merge of the ranks' shard files (each a database file in its own filter order)
+    by (filter value, key) -- merge_stage2's role (db_builder.cpp:392-458).  Returns (total k-mers, total entries)."""
+    L = _lib()
+    h = _header(sequence_type, tree_index, newick, kmer_size, omega)
+    arr = (C.c_char_p * len(shard_paths))(*[str(p).encode() for p in shard_paths])
+    nk, ne, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = L.ipkgpu_db_merge_files(C.byref(h), arr, len(shard_paths), str(path).encode(), C.byref(nk), C.byref(ne), C.byref(nb))
+    if rc != 0:
+        raise IpkGpuError(rc, L.ipkgpu_db_merge_last_error().decode())
+    return int(nk.value), int(ne.value)

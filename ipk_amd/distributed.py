@@ -186,26 +186,26 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
     return db, first
 
 
-def write_db_file(path, sequence_type, tree_index, newick, kmer_size, omega, keys, key_offsets, branches, scores,
-                  filter_values, order, workdir, dist=None, world=1, rank=0):
-    """Database file from the ranks' shards.  One rank: written directly in its filter order.  Several ranks: every
-    rank drops its shard into workdir/shards (the reference's on-disk mode leaves its batches in workdir/hashmaps the
-    same way, db_builder.cpp:460-464), rank 0 merges them by filter value (dbfile.merge_shards).
+def write_db_file(path, sequence_type, tree_index, newick, kmer_size, omega, write_shard, workdir, dist=None, world=1, rank=0):
+    """Database file from the ranks' shards.  `write_shard(file)` writes THIS rank's shard -- its k-mers in its own filter
+    order -- as a database file (dbfile.write_db_device / dbfile.write_db) and returns nothing.  One rank: that file is the
+    database.  Several ranks: every rank drops its shard into workdir/shards (the reference's on-disk mode leaves its batches
+    in workdir/hashmaps the same way, db_builder.cpp:460-464) and rank 0 merges the shard files by (filter value, key),
+    streaming (dbfile.merge_shard_files = ipkgpu_db_merge_files: merge_stage2's role, db_builder.cpp:392-458).
     Returns (total k-mers, total entries) on the writing rank, None elsewhere."""
     from . import dbfile
     if world == 1:
-        dbfile.write_db(path, sequence_type, tree_index, newick, kmer_size, omega, keys, key_offsets, branches, scores,
-                        filter_values, order)
-        return len(keys), int(key_offsets[-1]) if len(key_offsets) else 0
+        write_shard(path)
+        return None
     sdir = os.path.join(workdir, "shards")
     os.makedirs(sdir, exist_ok=True)
-    mine = os.path.join(sdir, f"shard{rank}.npz")
-    dbfile.write_shard(mine, keys, key_offsets, branches, scores, filter_values)
+    mine = os.path.join(sdir, f"shard{rank}.ipk")
+    write_shard(mine)
     dist.barrier()
     out = None
     if rank == 0:
-        paths = [os.path.join(sdir, f"shard{r}.npz") for r in range(world)]
-        out = dbfile.merge_shards(path, sequence_type, tree_index, newick, kmer_size, omega, paths)
+        paths = [os.path.join(sdir, f"shard{r}.ipk") for r in range(world)]
+        out = dbfile.merge_shard_files(path, sequence_type, tree_index, newick, kmer_size, omega, paths)
     dist.barrier()
     os.remove(mine)
     return out
