@@ -56,7 +56,10 @@ def ipk():
               help="directory holding <prefix>.raxml.ancestralProbs / .raxml.ancestralTree [searched in the workdir if absent]")
 @click.option("--ar-only", is_flag=True, help="(ignored)")
 @click.option("--ar-config", type=click.Path(), help="(ignored)")
-@click.option("--keep-positions", is_flag=True, help="unsupported on this engine")
+@click.option("--keep-positions", is_flag=True,
+              help="(ipk-aa-pos) NOT SUPPORTED by this command: the scoring call exists (ipkgpu_score_groups_positions: per branch, "
+                   "the kept score's window position) but only with per-branch output; the database of positioned entries -- "
+                   "i2l's positioned phylo_kmer and its serialisation, un-vendored -- has no container here, so no file could be written.")
 @click.option("--uncompressed", is_flag=True, help="(ignored, as in the reference)")
 @click.option("--threads", type=int, default=1, show_default=True, help="host threads of the probability loader")
 @click.option("-o", "--output", default=None, help="output file [workdir/DB.ipk]")
@@ -73,8 +76,12 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
     from ipk_amd import dbfile, distributed
     from ipk_amd.loader import AncestralProbs
 
-    if merge_branches or keep_positions:
-        raise click.UsageError("--merge-branches / --keep-positions are not supported")
+    if keep_positions:
+        raise click.UsageError("--keep-positions: positions are scored (ipkgpu_score_groups_positions, per-branch output) but there is no "
+                               "database container for positioned entries here (i2l's positioned phylo_kmer is un-vendored); "
+                               "build without the flag")
+    if merge_branches:
+        raise click.UsageError("--merge-branches is not supported (the reference only guards it, main.cpp:31-37)")
     from ipk_amd import tree as T
     sigma = 4 if states == "nucl" else 20
     if not 2 <= k <= ipk_amd.max_k(sigma):

@@ -17,6 +17,7 @@
 // here in float so the matrices match what IPK would compute; it is an assumption about un-vendored
 // code (parity unpinned).
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -24,6 +25,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -123,6 +125,17 @@ inline const char* parse_plain_decimal(const char* col, float& out)
     if (c == col) return nullptr;
     out = x;
     return c;
+}
+
+// Worker threads when the caller does not say: the cores this process may run on (affinity mask), at most 16 -- a GPU's
+// share of a multi-GPU host; IPKGPU_THREADS overrides.
+inline uint32_t default_threads()
+{
+    if (const char* e = getenv("IPKGPU_THREADS")) { const long v = atol(e); if (v > 0) return (uint32_t)std::min<long>(v, 256); }
+    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<uint32_t>(n, (uint32_t)std::max(1, CPU_COUNT(&set)));
+    return std::min<uint32_t>(n, 16u);
 }
 
 const int AA_FROM_RAXML[20] = {1, 8, 11, 3, 6, 15, 16, 2, 5, 4, 7, 14, 0, 9, 10, 12, 13, 17, 18, 19};
@@ -250,7 +263,7 @@ int ipkgpu_ar_open(const char* path, uint32_t sigma, ipkgpu_ar** out)
     if (p < end) p = line_end(p, end) + 1;                           // skip the header
     struct Ev { const char* at; size_t len; };
     const size_t body = p < end ? (size_t)(end - p) : 0;
-    uint32_t nth = (uint32_t)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), body / (8u << 20) + 1);
+    uint32_t nth = (uint32_t)std::min<size_t>(default_threads(), body / (8u << 20) + 1);
     std::vector<std::vector<Ev>> evs(nth);
     auto scan = [&](uint32_t t) {
         const char* a = p + body * t / nth;
@@ -322,7 +335,7 @@ int ipkgpu_ar_read_nodes(ipkgpu_ar* ar, const uint32_t* node_idx, uint32_t n, fl
     if (!ar || !node_idx || !out) { g_ar_err = "null argument"; return IPKGPU_ERR_INVALID; }
     for (uint32_t i = 0; i < n; ++i)
         if (node_idx[i] >= ar->labels.size()) { g_ar_err = "node index out of range"; return IPKGPU_ERR_INVALID; }
-    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads == 0) n_threads = default_threads();
     n_threads = std::min<uint32_t>(n_threads, std::max(1u, n));
     std::atomic<uint32_t> next{0};
     std::atomic<int> bad{-1};
