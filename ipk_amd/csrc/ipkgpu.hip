@@ -79,6 +79,8 @@ struct ipkgpu_ctx {
     // compressed table form (exact-partition variant on sparse key spaces; comp_table.hpp): no dense ctx->table
     bool table_compressed = false;
     DevBuf rank, vaddr, ucnt, qpack, xstart, pcounts;
+    DevBuf cvals, coff, croom;          // compressed output of the chunk-fed reduce: values, their offsets per (group, bucket), room
+    bool comp_own_vals = false;         // the compressed values live in cvals / coff (chunked pool) instead of in place in the pool
     std::vector<uint32_t> h_branch;     // host copy of the last call's branch ids (source of an asynchronous upload)
     uint32_t comp_nb = 0, comp_stride = 0, comp_tbl = 0;
     double pairs_per_window = 0;      // calibration of the pair pool from the previous call
@@ -320,7 +322,8 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
                       &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
                       &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->mask,
-                      &ctx->rank, &ctx->vaddr, &ctx->ucnt, &ctx->qpack, &ctx->xstart, &ctx->pcounts, &ctx->ptrs};
+                      &ctx->rank, &ctx->vaddr, &ctx->ucnt, &ctx->qpack, &ctx->xstart, &ctx->pcounts, &ctx->ptrs,
+                      &ctx->cvals, &ctx->coff, &ctx->croom};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& b : ctx->free_blocks) (void)hipFree(b.first);
     ipkgpu_comm_release(ctx);
@@ -481,21 +484,24 @@ int launch_stream_overflow(ipkgpu_ctx* ctx, const StreamParams& sp)
 }
 
 template <int SIGMA, int K>
-int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* table)
+int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* table, bool compress)
 {
     constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
-    if constexpr (TBL == 0) { (void)n_gb; (void)T; (void)table; return fail(ctx, IPKGPU_ERR_INVALID, "stream variant unsupported"); }
+    if constexpr (TBL == 0) { (void)n_gb; (void)T; (void)table; (void)compress; return fail(ctx, IPKGPU_ERR_INVALID, "stream variant unsupported"); }
     else {
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
         constexpr int NT = TBL <= 16384 ? 512 : 1024;
-        constexpr size_t lds = (size_t)TBL * 4;
-        auto kern = reduce_buckets_kernel<TBL, NT>;
-        if (lds > 64 * 1024)
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(),
-                           ctx->gboff.as<uint64_t>(), ctx->clist.as<uint2>(), NB, T, table, ctx->mask.as<uint32_t>(), ctx->mask_words);
-        HIP_TRY(ctx, hipGetLastError());
-        return IPKGPU_OK;
+        const size_t lds = (size_t)TBL * 4 + (compress ? (NT / 64 + 1) * 4 : 0);
+        auto launch = [&](auto kern) -> int {
+            if (lds > 64 * 1024)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(n_gb), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(),
+                               ctx->gboff.as<uint64_t>(), ctx->clist.as<uint2>(), NB, T, table, ctx->mask.as<uint32_t>(), ctx->mask_words,
+                               ctx->cvals.as<uint2>(), ctx->coff.as<uint64_t>(), ctx->rank.as<uint32_t>(), ctx->vaddr.as<uint64_t>(), ctx->ucnt.as<uint32_t>());
+            HIP_TRY(ctx, hipGetLastError());
+            return IPKGPU_OK;
+        };
+        return compress ? launch(reduce_buckets_kernel<TBL, NT, true>) : launch(reduce_buckets_kernel<TBL, NT, false>);
     }
 }
 
@@ -749,9 +755,9 @@ int dispatch_quad_pass1(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, const Strea
 #undef M_Q1
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
 }
-int dispatch_stream_pass2(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t n_gb, uint64_t T, uint32_t* table)
+int dispatch_stream_pass2(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t n_gb, uint64_t T, uint32_t* table, bool compress)
 {
-#define M_P2(S_, K_) return launch_stream_pass2<S_, K_>(ctx, n_gb, T, table)
+#define M_P2(S_, K_) return launch_stream_pass2<S_, K_>(ctx, n_gb, T, table, compress)
     IPK_DISPATCH(sigma, k, M_P2);
 #undef M_P2
     return fail(ctx, IPKGPU_ERR_INVALID, "unsupported sigma/k");
@@ -830,8 +836,9 @@ uint32_t xp_bucket_slots(uint32_t sigma, uint32_t k)
 CompTable comp_table(const ipkgpu_ctx* ctx)
 {
     CompTable ct;
-    ct.mask = ctx->mask.as<uint32_t>(); ct.rank = ctx->rank.as<uint32_t>(); ct.vaddr = ctx->vaddr.as<uint64_t>(); ct.pool = ctx->pool.as<uint2>();
-    ct.off = ctx->gboff.as<uint64_t>(); ct.mask_words = ctx->mask_words;
+    ct.mask = ctx->mask.as<uint32_t>(); ct.rank = ctx->rank.as<uint32_t>(); ct.vaddr = ctx->vaddr.as<uint64_t>();
+    ct.pool = ctx->comp_own_vals ? ctx->cvals.as<uint2>() : ctx->pool.as<uint2>();
+    ct.off = ctx->comp_own_vals ? ctx->coff.as<uint64_t>() : ctx->gboff.as<uint64_t>(); ct.mask_words = ctx->mask_words;
     ct.NB = ctx->comp_nb; ct.stride = ctx->comp_stride; ct.TBL = ctx->comp_tbl;
     return ct;
 }
@@ -1098,14 +1105,23 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     //                     64 GB less at cfg4, 40 % fewer bytes moved; 90.5 vs 92.0 ms through dense tables)
     const bool use_xp = XNB != 0 && (ctx->opt_variant == 3 || ctx->opt_variant == 4 || (ctx->opt_variant == 0 && NBK == 0));
     const bool xp_compress = use_xp && ctx->opt_variant != 3;
-    const bool use_stream = !use_xp && NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2 || ctx->opt_variant == 5);
+    const bool use_stream = !use_xp && NBK != 0 && NBK <= 2048 && (ctx->opt_variant == 0 || ctx->opt_variant == 2 || ctx->opt_variant == 5 ||
+                                                                   ctx->opt_variant == 6 || ctx->opt_variant == 7);
     // pass 1 of the stream variant: the quad kernel (kernels_quad.hpp) where it exists (DNA k = 8..12), variant 2 forces the
     // first-generation score_stream_kernel, variant 5 asks for the quad kernel explicitly
     const bool use_quad = use_stream && ctx->opt_variant != 2 && quad_supported(pl.sigma, pl.k);
+    // The chunk-fed reduce ends in the compressed table form (occupancy bits + rank + the non-empty slots' score codes, comp_table.hpp)
+    // where the scored k-mers fill the key space sparsely: DNA k = 11, 12 (cfg3: 38 % of 4^12 slots per group -- no 64 MB dense table
+    // per group to write and read back); variant 6 forces it for any stream (sigma, k), variant 7 forces dense tables.  The big-list
+    // windows then always go through the pool (the atomic kernel needs dense tables), which bounds the field widths of their queue.
+    const bool pool_ovf_ok = gb < (1u << 22) && n_mats < (1u << 21) && pl.nwin < (1u << 21);
+    const bool s_compress = use_stream && pool_ovf_ok && ctx->opt_variant != 7 && ctx->opt_variant != 2 &&
+                            (ctx->opt_variant == 6 || (ctx->opt_variant == 0 && stream_tbl_value(pl.sigma, pl.k) == 32768u && pl.sigma == 4));
+    ctx->comp_own_vals = false;
     const uint32_t SNW = use_quad ? quad_waves(pl.sigma, pl.k) : stream_waves(pl.sigma, pl.k);
     const uint32_t STW = use_quad ? quad_tile(pl.sigma, pl.k) : stream_tile(pl.sigma, pl.k);
     const uint32_t s_tiles_per_mat = (pl.nwin + STW - 1) / STW;
-    if (!xp_compress) {
+    if (!xp_compress && !s_compress) {
         RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 4));
         p.table = ctx->table.p;
     }
@@ -1261,7 +1277,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // a handful of big-list windows (< 0.2 % of the batch) are cheaper through the atomic kernel after pass 2 than
         // through sort + pool kernel; flat posteriors put a large share of the pairs there and need the pool
-        const bool ovf_in_pool = (uint64_t)n_ovf * IPK_OVF_POOL_RATIO >= windows && gb < (1u << 22) && n_mats < (1u << 21) && pl.nwin < (1u << 21);
+        const bool ovf_in_pool = n_ovf > 0 && ((uint64_t)n_ovf * IPK_OVF_POOL_RATIO >= windows || s_compress) && pool_ovf_ok;
         if (ovf_in_pool) {
             RC_TRY(ensure(ctx, ctx->tmp_a, (size_t)n_ovf * 8));
             RC_TRY(ensure(ctx, ctx->tmp_b, (size_t)n_ovf * 8));
@@ -1300,13 +1316,32 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         HIP_TRY(ctx, hipMemsetAsync(ctx->gbcnt.p, 0, n_gb * 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->gbcur.p, 0, n_gb * 4, ctx->stream));
         RC_TRY(ensure(ctx, ctx->clist, std::max<uint64_t>(n_used, 1) * 8));
+        if (s_compress) {
+            RC_TRY(ensure(ctx, ctx->croom, 2 * n_gb * 4));                  // [pairs per (group, bucket) | room of its values]
+            HIP_TRY(ctx, hipMemsetAsync(ctx->croom.p, 0, n_gb * 4, ctx->stream));
+        }
         if (n_used) {
             hipLaunchKernelGGL(chunk_hist_kernel, dim3(std::min<uint32_t>((n_used + 255) / 256, 2048u)), dim3(256), 0, ctx->stream,
                                ctx->desc.as<unsigned long long>(), n_used, ctx->gbcnt.as<uint32_t>(),
-                               use_quad ? p.emitted : (unsigned long long*)nullptr);
+                               use_quad ? p.emitted : (unsigned long long*)nullptr, s_compress ? ctx->croom.as<uint32_t>() : (uint32_t*)nullptr);
             HIP_TRY(ctx, hipGetLastError());
         }
         RC_TRY(scan_u32(ctx, ctx->gbcnt.as<uint32_t>(), n_gb, ctx->gboff.as<uint64_t>()));
+        if (s_compress) {
+            // where the slices' values go: room for min(pairs, slots) values per (group, bucket), scanned; the buffer itself is sized
+            // from what the host knows without another wait -- no more values than pairs, no more pairs than the used chunks hold
+            const uint32_t TBLv = stream_tbl_value(pl.sigma, pl.k);
+            hipLaunchKernelGGL(comp_slice_room_kernel, dim3((uint32_t)((n_gb + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->croom.as<uint32_t>(), (uint32_t)n_gb, NBK, pl.table_size, TBLv, ctx->croom.as<uint32_t>() + n_gb);
+            HIP_TRY(ctx, hipGetLastError());
+            RC_TRY(ensure(ctx, ctx->coff, (n_gb + 1) * 8));
+            RC_TRY(scan_u32(ctx, ctx->croom.as<uint32_t>() + n_gb, n_gb, ctx->coff.as<uint64_t>()));
+            const uint64_t max_vals = std::min<uint64_t>((uint64_t)n_used * CH, (uint64_t)gb * pl.table_size);
+            RC_TRY(ensure(ctx, ctx->cvals, (max_vals / 2 + n_gb + 1) * 8 + 256));   // (+256: km_write_c_kernel reads up to 32 values from a row's start)
+            RC_TRY(ensure(ctx, ctx->rank, (size_t)gb * (ctx->mask_words / 2) * 4));
+            RC_TRY(ensure(ctx, ctx->vaddr, (size_t)gb * (ctx->mask_words / 2) * 8));
+            RC_TRY(ensure(ctx, ctx->ucnt, n_gb * 4));
+        }
         if (n_used) {
             hipLaunchKernelGGL(chunk_scatter_kernel, dim3((n_used + 255) / 256), dim3(256), 0, ctx->stream,
                                ctx->desc.as<unsigned long long>(), n_used, ctx->gboff.as<uint64_t>(), ctx->gbcur.as<uint32_t>(),
@@ -1314,9 +1349,13 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
             HIP_TRY(ctx, hipGetLastError());
         }
         const int ev_c = sw.mark();
-        RC_TRY(dispatch_stream_pass2(ctx, pl.sigma, pl.k, (uint32_t)n_gb, pl.table_size, ctx->table.as<uint32_t>()));
+        RC_TRY(dispatch_stream_pass2(ctx, pl.sigma, pl.k, (uint32_t)n_gb, pl.table_size, ctx->table.as<uint32_t>(), s_compress));
         const int ev_d = sw.mark();
         if (n_ovf > 0 && !ovf_in_pool) RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
+        if (s_compress) {
+            ctx->table_compressed = true; ctx->comp_own_vals = true;
+            ctx->comp_nb = NBK; ctx->comp_stride = 1; ctx->comp_tbl = stream_tbl_value(pl.sigma, pl.k);
+        }
         HIP_TRY(ctx, hipMemcpyAsync(&ctx->emitted_host, p.emitted, 8, hipMemcpyDeviceToHost, ctx->stream));   // (one wait for both)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->emitted_fetched = true;

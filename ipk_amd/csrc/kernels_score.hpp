@@ -298,8 +298,11 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
 // through the slow path of the append: at cfg2 (122 pairs per window, 64 buckets per wavefront) 512-pair chunks make the scoring kernel
 // 4 % faster than 256; with 512 buckets per wavefront (k = 11, 12: TBL = 32768) the chunks fill too slowly and 256 stays better
 // (cfg3 share: +1.7 % with 512).
-template <uint32_t TBL> constexpr uint32_t chunk_pairs() { return TBL == 16384 ? 512u : 256u; }
-inline uint32_t chunk_pairs_rt(uint32_t tbl) { return tbl == 16384 ? 512u : 256u; }
+#ifndef IPK_CH512_TBL
+#define IPK_CH512_TBL 0u         // tuning: a second table size whose chunks hold 512 pairs (32768: DNA k = 11, 12)
+#endif
+template <uint32_t TBL> constexpr uint32_t chunk_pairs() { return (TBL == 16384 || TBL == IPK_CH512_TBL) ? 512u : 256u; }
+inline uint32_t chunk_pairs_rt(uint32_t tbl) { return (tbl == 16384 || tbl == IPK_CH512_TBL) ? 512u : 256u; }
 constexpr uint32_t CHUNK_NONE = 0xFFFFFFFFu;
 constexpr uint32_t ALLOC_BATCH = 32;         // chunk ids a wavefront draws per global atomic
 constexpr uint32_t SUB = 1;                  // open chunks per (wave, bucket); >1 spreads a bucket over lane-interleaved chunks
@@ -708,13 +711,17 @@ __global__ __launch_bounds__(256) void ovf_group_keys_kernel(const unsigned long
 // descriptors with at most a few thousand workgroups: one atomic per workgroup on the total (a single word takes
 // ~88 returning atomics per microsecond chip-wide, so one per wavefront of descriptors would cost milliseconds).
 __global__ __launch_bounds__(256) void chunk_hist_kernel(const unsigned long long* __restrict__ desc, uint32_t n,
-                                                         uint32_t* __restrict__ cnt, unsigned long long* __restrict__ pairs)
+                                                         uint32_t* __restrict__ cnt, unsigned long long* __restrict__ pairs,
+                                                         uint32_t* __restrict__ gb_pairs /* optional: pairs per (group, bucket) */)
 {
     __shared__ unsigned long long wsum[4];
     unsigned long long c = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const unsigned long long d = desc[i];
-        if ((uint32_t)d != 0u) atomicAdd(&cnt[(uint32_t)(d >> 32)], 1u);
+        if ((uint32_t)d != 0u) {
+            atomicAdd(&cnt[(uint32_t)(d >> 32)], 1u);
+            if (gb_pairs) atomicAdd(&gb_pairs[(uint32_t)(d >> 32)], (uint32_t)d);
+        }
         c += (uint32_t)d;
     }
     if (pairs) {
@@ -757,11 +764,78 @@ __device__ __forceinline__ void store_slice_mask(const uint32_t* tab, uint32_t n
 // pass 2: one workgroup per (group, bucket): LDS max-reduce of the bucket's chunks, then the table slice.
 // Each wave takes two chunks per trip and issues all of their pair loads (8 x 512 B) before the first
 // LDS atomic, so ~4 KiB per wave are in flight.
+// Room for the values of a compressed slice (below): a (group, bucket) holds at most min(its pairs, its slots) distinct keys;
+// sizes in 8-byte units (the CompTable offsets address a uint2 array).
+__global__ __launch_bounds__(256) void comp_slice_room_kernel(const uint32_t* __restrict__ gb_pairs, uint32_t n_gb, uint32_t NB, uint64_t T,
+                                                              uint32_t TBL, uint32_t* __restrict__ room)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_gb) return;
+    const uint32_t b = i % NB;
+    const uint32_t nslots = (uint32_t)min((uint64_t)TBL, T - (uint64_t)b * TBL);
+    room[i] = (min(gb_pairs[i], nslots) + 1u) / 2u;
+}
+
+// The compressed form of a finished table slice (comp_table.hpp): occupancy bits, rank of every 64-slot block, the non-empty
+// slots' score codes in slot order at `vals`, and the blocks' value addresses.  `tab` = the slice in LDS (TBL slots, then room for
+// NT / 64 + 1 words); every thread of the workgroup calls it after the barrier that ends the reduction.
 template <uint32_t TBL, int NT>
+__device__ __forceinline__ void compress_slice(uint32_t* tab, uint32_t nslots, uint32_t* vals, uint32_t* mrow, uint32_t* rrow,
+                                               uint64_t* arow, uint32_t* ucnt_gb)
+{
+    // every wave owns a contiguous range of 64-slot blocks: totals per wave, then each wave runs its own offsets
+    constexpr uint32_t NWV = NT / 64, MAXBLK = (TBL + 63) / 64, BPW = (MAXBLK + NWV - 1) / NWV;
+    uint32_t* wtot = tab + TBL;                                   // [NWV + 1]
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t nblk = (nslots + 63) / 64;
+    const uint32_t b_lo = min(nblk, wave * BPW), b_hi = min(nblk, b_lo + BPW);
+    // the wave's blocks in registers (all LDS reads in flight together), then counting and writing run on registers
+    uint32_t vr[BPW];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < BPW; ++j) {
+        const uint32_t z = (b_lo + j) * 64 + lane;
+        vr[j] = (b_lo + j < b_hi && z < nslots) ? tab[z] : 0u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < BPW; ++j) mine += (uint32_t)__popcll(__ballot(vr[j] != 0u));
+    if (lane == 0) wtot[wave] = mine;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+    for (uint32_t w = 0; w < NWV; ++w) { const uint32_t t = wtot[w]; if (w < wave) base += t; all += t; }
+    // lane j collects block j's rank and bits; they leave as coalesced stores after the loop (BPW <= 64)
+    static_assert(BPW <= 64, "one lane per block of the wave");
+    uint32_t my_base = 0;
+    uint64_t my_m = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < BPW; ++j) {
+        const uint32_t blk = b_lo + j;
+        const uint64_t m = __ballot(vr[j] != 0u);
+        if (lane == j) { my_base = base; my_m = m; }
+        if (blk < b_hi && vr[j] != 0u) vals[base + mbcnt(m)] = vr[j];
+        base += (uint32_t)__popcll(m);
+    }
+    if (b_lo + lane < b_hi) {
+        const uint32_t blk = b_lo + lane;
+        rrow[blk] = my_base;
+        *reinterpret_cast<uint2*>(mrow + 2 * blk) = make_uint2((uint32_t)my_m, (uint32_t)(my_m >> 32));
+        arow[blk] = (uint64_t)(vals + my_base);
+    }
+    if (threadIdx.x == 0) *ucnt_gb = all;
+}
+
+// COMPRESS: the slice leaves in the compressed form instead of as TBL dense slots -- for key spaces the scored k-mers fill
+// sparsely (DNA k = 12: 38 % of a group's 16.8 M slots at cfg3) the dense tables are the larger part of what pass 2 writes and
+// the key-major writer reads.  The values of (group, bucket) go to cvals + coff[group * NB + bucket] (8-byte units; room for
+// min(pairs, slots) values each, comp_slice_room_kernel).
+template <uint32_t TBL, int NT, bool COMPRESS = false>
 __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restrict__ pool,
                                                            const uint64_t* __restrict__ off, const uint2* __restrict__ list,
                                                            uint32_t NB, uint64_t T, uint32_t* __restrict__ table,
-                                                           uint32_t* __restrict__ mask, uint64_t mask_words)
+                                                           uint32_t* __restrict__ mask, uint64_t mask_words,
+                                                           uint2* __restrict__ cvals, const uint64_t* __restrict__ coff,
+                                                           uint32_t* __restrict__ rank, uint64_t* __restrict__ vaddr,
+                                                           uint32_t* __restrict__ ucnt)
 {
     constexpr uint32_t CH = chunk_pairs<TBL>();
     extern __shared__ __align__(16) unsigned char smem[];
@@ -803,6 +877,11 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
         }
     }
     __syncthreads();
+    if constexpr (COMPRESS) {
+        compress_slice<TBL, NT>(tab, nslots, reinterpret_cast<uint32_t*>(cvals + coff[gb]), mask + (size_t)g * mask_words + (key0 >> 5),
+                                rank + (size_t)g * (mask_words / 2) + (key0 >> 6), vaddr + (size_t)g * (mask_words / 2) + (key0 >> 6), ucnt + gb);
+        return;
+    }
     uint32_t* dst = table + (size_t)g * T + key0;
     if ((nslots & 3u) == 0 && ((((size_t)g * T + key0) & 3u) == 0)) {
         for (uint32_t i = threadIdx.x; i < nslots / 4; i += NT) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<uint4*>(tab)[i];
@@ -1210,49 +1289,9 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(uint2* __restrict__ p
         }
         if (mask) store_slice_mask(tab, nslots, mask + (size_t)g * mask_words + (key0 >> 5), NT);
     } else {
-        // every wave owns a contiguous range of 64-slot blocks: totals per wave, then each wave runs its own offsets
-        constexpr uint32_t NWV = NT / 64, MAXBLK = (TBL + 63) / 64, BPW = (MAXBLK + NWV - 1) / NWV;
-        uint32_t* wtot = tab + TBL;                                   // [NWV + 1]
-        const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-        const uint32_t nblk = (nslots + 63) / 64;
-        const uint32_t b_lo = min(nblk, wave * BPW), b_hi = min(nblk, b_lo + BPW);
-        // the wave's blocks in registers (all LDS reads in flight together), then counting and writing run on registers
-        uint32_t vr[BPW];
-        uint32_t mine = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < BPW; ++j) {
-            const uint32_t z = (b_lo + j) * 64 + lane;
-            vr[j] = (b_lo + j < b_hi && z < nslots) ? tab[z] : 0u;
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < BPW; ++j) mine += (uint32_t)__popcll(__ballot(vr[j] != 0u));
-        if (lane == 0) wtot[wave] = mine;
-        __syncthreads();
-        uint32_t base = 0, all = 0;
-        for (uint32_t w = 0; w < NWV; ++w) { const uint32_t t = wtot[w]; if (w < wave) base += t; all += t; }
-        uint32_t* vals = reinterpret_cast<uint32_t*>(pool + r0);      // in place: every pair of the range has been consumed
-        uint32_t* mrow = mask + (size_t)g * mask_words + (key0 >> 5);
-        uint32_t* rrow = rank + (size_t)g * (mask_words / 2) + (key0 >> 6);
-        uint64_t* arow = vaddr + (size_t)g * (mask_words / 2) + (key0 >> 6);      // the block's first value, as an address (km_write_c_kernel)
-        // lane j collects block j's rank and bits; they leave as coalesced stores after the loop (BPW <= 64)
-        static_assert(BPW <= 64, "one lane per block of the wave");
-        uint32_t my_base = 0;
-        uint64_t my_m = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < BPW; ++j) {
-            const uint32_t blk = b_lo + j;
-            const uint64_t m = __ballot(vr[j] != 0u);
-            if (lane == j) { my_base = base; my_m = m; }
-            if (blk < b_hi && vr[j] != 0u) vals[base + mbcnt(m)] = vr[j];
-            base += (uint32_t)__popcll(m);
-        }
-        if (b_lo + lane < b_hi) {
-            const uint32_t blk = b_lo + lane;
-            rrow[blk] = my_base;
-            *reinterpret_cast<uint2*>(mrow + 2 * blk) = make_uint2((uint32_t)my_m, (uint32_t)(my_m >> 32));
-            arow[blk] = (uint64_t)(vals + my_base);
-        }
-        if (threadIdx.x == 0) ucnt[gb] = all;
+        // in place: every pair of the range has been consumed
+        compress_slice<TBL, NT>(tab, nslots, reinterpret_cast<uint32_t*>(pool + r0), mask + (size_t)g * mask_words + (key0 >> 5),
+                                rank + (size_t)g * (mask_words / 2) + (key0 >> 6), vaddr + (size_t)g * (mask_words / 2) + (key0 >> 6), ucnt + gb);
     }
 }
 

@@ -444,3 +444,35 @@ def _oracle_db(mats, groups, k, eps):
         for key, s in zip(keys.tolist(), scores.view(np.uint32).tolist()):
             full.setdefault(key, []).append((gid, s))
     return full, emitted
+
+
+@pytest.mark.parametrize("sigma,k,sites,alpha", [(4, 8, 90, 0.1), (4, 10, 150, 0.05), (4, 12, 60, 0.05), (20, 4, 30, 0.03)],
+                         ids=["dna_k8", "dna_k10", "dna_k12", "aa_k4"])
+@pytest.mark.parametrize("variant", [6, 7], ids=["compressed", "dense"])
+def test_chunk_fed_reduce_in_both_table_forms(sigma, k, sites, alpha, variant):
+    """The LDS reduce over the chunked pair pool ends either in dense per-group tables or in the compressed form (occupancy
+    bits + rank + score codes; the default for DNA k = 11, 12): both must give the oracle's sets, per branch and key-major."""
+    n_groups = 5
+    mats = synth_matrices(2 * n_groups, sites, sigma, alpha, 4100 + k)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 11, 2)
+    eps = co.log_threshold(1.5, sigma, k)
+    eng = ipk_amd.Engine(0)
+    try:
+        eng.set_option("variant", variant)
+        check_against_oracle(eng, mats, groups, k, eps)
+        parts = eng.score_groups_keymajor(mats, groups, k, eps, n_owners=2)
+        full, emitted = _oracle_db(mats, groups, k, eps)
+        assert parts.emitted == emitted and parts.num_entries == sum(len(v) for v in full.values())
+        for owner in range(2):
+            db = eng.merge_parts_ptrs(sigma, k, owner, 2, [parts.counts_ptr() + 4 * owner * parts.slots],
+                                      [parts.entries_ptr() + 8 * int(parts.owner_offsets[owner])])
+            keys, off = db.keys(), db.key_offsets()
+            br, sc = db.entries()
+            for i in range(0, len(keys), max(1, len(keys) // 300)):
+                e = full[int(keys[i])]
+                assert [int(b) for b in br[off[i]:off[i + 1]]] == [b for b, _ in e]
+                assert [int(x) for x in sc[off[i]:off[i + 1]].view(np.uint32)] == [x for _, x in e]
+            db.free()
+        parts.free()
+    finally:
+        eng.close()
