@@ -285,6 +285,7 @@ def main():
         step(True)
     barrier()
     last_kernel = eng.last_main_kernel()
+    tables_compressed = eng.last_tables_compressed()
     score_ms, launches, total_ms, compact_ms, prefix_ms = acc["score"], acc["launches"], acc["total"], acc["compact"], acc["prefix"]
     elapsed = time.perf_counter() - t_start
     rank_ms = [elapsed / args.steps * 1e3]
@@ -349,6 +350,10 @@ def main():
             kline("score_xp_kernel<WRITE>", per_launch("xp_write"), mb + p_bytes)       # the pairs leave here
             kline("reduce_ranges_kernel", per_launch("reduce"), p_bytes + e_bytes / 2)  # pairs in, one 4-B score code per entry out
             kline("km_write_c_kernel", per_launch("km_write"), e_bytes / 2 + e_bytes)   # score codes in, 8-B entries out
+        elif tables_compressed:
+            kline(main_kernel, avg_main_ms, b_alg)
+            kline("reduce_buckets_kernel<COMPRESS>", per_launch("reduce"), p_bytes + e_bytes / 2)        # pairs in, one 4-B score code per entry out
+            kline("km_write_c_kernel", per_launch("km_write"), e_bytes / 2 + e_bytes)                  # score codes in, 8-B entries out
         else:
             kline(main_kernel, avg_main_ms, b_alg)
             kline("reduce_buckets_kernel", per_launch("reduce"), p_bytes + 4.0 * (sigma ** k) * ng)   # pairs in, dense tables out

@@ -79,6 +79,9 @@ const char* ipkgpu_last_error(const ipkgpu_ctx* ctx);
 /* Name of the dominant kernel of the context's last scoring call ("score_quad_kernel", "score_stream_kernel",
  * "score_xp_kernel", "score_tiles_kernel"): what IPKGPU_T_SCORE_MAIN timed. */
 const char* ipkgpu_last_main_kernel(const ipkgpu_ctx* ctx);
+/* 1 if the last scoring batch left its per-group tables in the compressed form (occupancy bits + rank + score codes: AA k=6,
+ * DNA k=11, 12), 0 for dense tables: tells the benchmark which reduce / key-major writer kernels ran. */
+int ipkgpu_last_tables_compressed(const ipkgpu_ctx* ctx);
 
 /* Diagnostics: -1 in the shipped build; in an IPK_EXEC_ASSERT build (ipk_amd/build.py, variant "execassert") the number of
  * times one of the kernels' exec-writing inline-asm helpers was entered with a partial exec mask (must be 0). */

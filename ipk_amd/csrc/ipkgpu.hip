@@ -2244,6 +2244,7 @@ extern "C" {
 
 const char* ipkgpu_db_write_last_error(void) { return g_write_err.c_str(); }
 const char* ipkgpu_last_main_kernel(const ipkgpu_ctx* ctx) { return ctx ? ctx->main_kernel : ""; }
+int ipkgpu_last_tables_compressed(const ipkgpu_ctx* ctx) { return ctx && ctx->table_compressed ? 1 : 0; }
 
 // Diagnostics: calls of the exec-writing asm helpers entered with a partial exec mask since the library was loaded
 // (IPK_EXEC_ASSERT builds only; -1 in the shipped build, which compiles the check away).

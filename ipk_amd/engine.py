@@ -18,7 +18,7 @@ T_TOTAL, T_PREFIX, T_SCORE, T_COMPACT, T_SCORE_LAUNCHES, T_SCORE_MAIN, T_SCORE_R
 
 # every symbol include/ipkgpu.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "ipkgpu_create", "ipkgpu_destroy", "ipkgpu_last_error", "ipkgpu_last_main_kernel", "ipkgpu_set_option",
+    "ipkgpu_create", "ipkgpu_destroy", "ipkgpu_last_error", "ipkgpu_last_main_kernel", "ipkgpu_last_tables_compressed", "ipkgpu_set_option",
     "ipkgpu_log_threshold", "ipkgpu_bits_per_symbol", "ipkgpu_kmer_batch", "ipkgpu_max_k",
     "ipkgpu_score_groups", "ipkgpu_score_groups_device",
     "ipkgpu_result_num_groups", "ipkgpu_result_group_ids", "ipkgpu_result_offsets",
@@ -59,6 +59,8 @@ def load_library():
     L.ipkgpu_last_error.argtypes = [C.c_void_p]
     L.ipkgpu_last_main_kernel.restype = C.c_char_p
     L.ipkgpu_last_main_kernel.argtypes = [C.c_void_p]
+    L.ipkgpu_last_tables_compressed.restype = C.c_int
+    L.ipkgpu_last_tables_compressed.argtypes = [C.c_void_p]
     L.ipkgpu_debug_exec_violations.restype = C.c_int64
     L.ipkgpu_debug_exec_violations.argtypes = [C.c_void_p]
     L.ipkgpu_set_option.restype = C.c_int
@@ -207,6 +209,9 @@ class Engine:
 
     def _err(self, rc):
         return IpkGpuError(rc, self._lib.ipkgpu_last_error(self._h).decode())
+
+    def last_tables_compressed(self):
+        return bool(self._lib.ipkgpu_last_tables_compressed(self._h))
 
     def last_main_kernel(self):
         return self._lib.ipkgpu_last_main_kernel(self._h).decode()
