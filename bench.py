@@ -92,7 +92,7 @@ def launch_ranks(n, argv):
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    limit = float(os.environ.get("IPK_BENCH_WATCHDOG_S", "1500")) + 60.0
+    limit = float(os.environ.get("IPK_BENCH_WATCHDOG_S", "900")) + 60.0
     pr = subprocess.Popen(cmd, env=env, start_new_session=True)       # stdout/stderr inherited: the JSON line passes straight through
     try:
         return pr.wait(timeout=limit)
@@ -113,9 +113,9 @@ def launch_ranks(n, argv):
 
 def start_watchdog():
     """A rank that waits for ever (a peer died inside a collective, a wedged transfer) must end with a non-zero code instead
-    of holding the node: a daemon thread ends the process after IPK_BENCH_WATCHDOG_S seconds (default 1500; 0 = off)."""
+    of holding the node: a daemon thread ends the process after IPK_BENCH_WATCHDOG_S seconds (default 900; 0 = off)."""
     import threading
-    limit = float(os.environ.get("IPK_BENCH_WATCHDOG_S", "1500"))
+    limit = float(os.environ.get("IPK_BENCH_WATCHDOG_S", "900"))
     if limit <= 0:
         return
 
