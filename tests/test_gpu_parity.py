@@ -476,3 +476,14 @@ def test_chunk_fed_reduce_in_both_table_forms(sigma, k, sites, alpha, variant):
         parts.free()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("k,alpha", [(12, 0.35), (11, 0.3), (12, 1.0)], ids=["k12_dense_rows", "k11_dense_rows", "k12_flat"])
+def test_row_per_lane_join_with_dense_rows(engine, k, alpha):
+    """DNA k = 11, 12 (row-per-lane final join): flattish columns give rows with dozens of passing pairs each, so the eight
+    rows of a key bucket reserve more than a chunk's worth in ONE round -- the bucket's chunk is closed early and crossed
+    again in the new chunk (LaneAppender::roll_at, the re-examination loop) -- and, fully flat, lists beyond the fast
+    path's capacity (big-list windows through the pool, compressed tables)."""
+    mats = synth_matrices(4, 70, 4, alpha, 700 + k)
+    check_against_oracle(engine, mats, [3, 3, 8, 8], k, co.log_threshold(1.5, 4, k))
+    check_against_oracle(engine, mats, [3, 3, 8, 8], k, co.log_threshold(1.5, 4, k), device=True)
