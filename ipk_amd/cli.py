@@ -212,6 +212,9 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
         click.echo(f"Filtering time: {t_filter * 1e3:.0f} ms")
         click.echo(f"Merge time: {t_write * 1e3:.0f} ms")
         click.echo(f"Output: {output} ({totals[0]} k-mers, {totals[1]} entries)")
+        click.echo("Note: the database layout is a reconstruction of i2l's Boost binary archive (i2l and Boost are not part of the "
+                   "reference tree): UNPINNED against a real .ipk -- ipk_amd/csrc/ipk_format.hpp is the one file that knows the bytes; "
+                   "IPKGPU_BOOST_ARCHIVE_VERSION sets the archive's library version (default 19).")
     db.free(); parts.free(); eng.close(); arp.close()
     if world > 1 and own_group:
         dist.destroy_process_group()

@@ -16,6 +16,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -29,6 +30,13 @@
 namespace ipkfmt {
 
 constexpr uint16_t BOOST_ARCHIVE_LIBRARY_VERSION = 19;      // Boost 1.74 .. 1.83 (ASSUMPTION: the build's Boost is unknown)
+// the version actually written: IPKGPU_BOOST_ARCHIVE_VERSION in the environment overrides the assumption (a reader built against
+// another Boost rejects an archive whose library version is newer than its own)
+inline uint16_t archive_library_version()
+{
+    if (const char* e = getenv("IPKGPU_BOOST_ARCHIVE_VERSION")) { const long v = atol(e); if (v > 0 && v < 65536) return (uint16_t)v; }
+    return BOOST_ARCHIVE_LIBRARY_VERSION;
+}
 constexpr uint64_t RECORD_HEAD_BYTES = 16;                   // key, filter value, entry count
 constexpr uint64_t ENTRY_BYTES = 8;                          // branch, score
 
@@ -50,7 +58,7 @@ inline std::vector<uint8_t> file_head(const char* sequence_type, uint64_t n_inde
 {
     std::vector<uint8_t> o;
     put_string(o, "serialization::archive");
-    put_v<uint16_t>(o, BOOST_ARCHIVE_LIBRARY_VERSION);
+    put_v<uint16_t>(o, archive_library_version());
     put_v<uint8_t>(o, 4); put_v<uint8_t>(o, 8); put_v<uint8_t>(o, 4); put_v<uint8_t>(o, 8);
     put_v<int32_t>(o, 1);
     put_string(o, sequence_type);

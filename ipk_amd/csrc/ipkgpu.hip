@@ -2322,13 +2322,18 @@ int ipkgpu_db_write(ipkgpu_ctx* ctx, ipkgpu_db* db, const ipkgpu_db_header* h, c
         RC_TRY(ensure(ctx, ctx->tmp_a, n * 4));
         RC_TRY(ensure(ctx, ctx->tmp_b, (n + 1) * 8));
         const auto t0 = std::chrono::steady_clock::now();
+        uint32_t* d_big = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 60);
+        HIP_TRY(ctx, hipMemsetAsync(d_big, 0, 4, ctx->stream));
         hipLaunchKernelGGL(db_record_sizes_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, db->d_order, db->d_key_off, n,
-                           ctx->tmp_a.as<uint32_t>());
+                           ctx->tmp_a.as<uint32_t>(), d_big);
         HIP_TRY(ctx, hipGetLastError());
         RC_TRY(scan_u32(ctx, ctx->tmp_a.as<uint32_t>(), n, ctx->tmp_b.as<uint64_t>()));
         std::vector<uint64_t> rec_off(n + 1);
+        uint32_t h_big = 0;
         HIP_TRY(ctx, hipMemcpyAsync(rec_off.data(), ctx->tmp_b.p, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&h_big, d_big, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_big) return fail(ctx, IPKGPU_ERR_INVALID, "a k-mer with 2^28 entries or more: record sizes are 32-bit");
         t_dev += since(t0);
         // pieces of whole records, two staging buffers: piece j+1 is packed and copied while piece j is written
         uint64_t max_rec = 0;

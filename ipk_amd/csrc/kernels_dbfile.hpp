@@ -8,14 +8,17 @@
 
 namespace ipkgpu {
 
-// rec_bytes[i] = size of the record of the i-th k-mer in filter order (u32: a k-mer has < 2^28 entries)
+// rec_bytes[i] = size of the record of the i-th k-mer in filter order (u32: a k-mer has at most one entry per branch group, and
+// a batch holds < 2^22 groups -- ipkgpu_db_write refuses databases whose largest record would not fit)
 __global__ __launch_bounds__(256) void db_record_sizes_kernel(const uint32_t* __restrict__ order, const uint64_t* __restrict__ key_off,
-                                                              uint64_t n_keys, uint32_t* __restrict__ rec_bytes)
+                                                              uint64_t n_keys, uint32_t* __restrict__ rec_bytes, uint32_t* __restrict__ too_big)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_keys) return;
     const uint32_t k = order[i];
-    rec_bytes[i] = (uint32_t)ipkfmt::record_bytes(key_off[k + 1] - key_off[k]);
+    const uint64_t n = key_off[k + 1] - key_off[k];
+    if (n >= (1ull << 28)) atomicOr(too_big, 1u);
+    rec_bytes[i] = (uint32_t)ipkfmt::record_bytes(n);
 }
 
 // One wavefront per k-mer of [i_lo, i_hi) (positions in filter order): head words by lane 0, entries by all lanes.
@@ -34,7 +37,9 @@ __global__ __launch_bounds__(256) void db_pack_kernel(const uint32_t* __restrict
     if (lane == 0) {
         uint32_t w[4];
         ipkfmt::record_head(keys[k], __float_as_uint(fv[k]), n, w);
-        *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);      // records are 8-byte sized: heads 8-byte aligned
+        // records are 16 + 8 n bytes: a head is 8-byte aligned, not 16 -- two 8-byte stores, not one uint4
+        reinterpret_cast<uint2*>(dst)[0] = make_uint2(w[0], w[1]);
+        reinterpret_cast<uint2*>(dst)[1] = make_uint2(w[2], w[3]);
     }
     uint2* e = reinterpret_cast<uint2*>(dst + ipkfmt::RECORD_HEAD_BYTES);
     for (uint64_t j = lane; j < n; j += 64) e[j] = entries[a + j];                // (branch, score bits) = the entry's bytes
