@@ -258,7 +258,7 @@ def test_randomised_small_cases(engine):
     rng = np.random.default_rng(int(os.environ.get("IPK_TEST_SEED", "20261003")))     # other seeds: extra sweeps by hand
     n_cases = int(os.environ.get("IPK_TEST_CASES", "80"))
     for case in range(n_cases):
-        engine.set_option("variant", int(rng.choice([0, 0, 0, 1, 3, 4])))   # every scoring variant must give the same sets
+        engine.set_option("variant", int(rng.choice([0, 0, 0, 1, 3, 4, 6, 7])))   # every scoring variant and table form must give the same sets
         sigma = 4 if rng.random() < 0.65 else 20
         k = int(rng.integers(2, 13)) if sigma == 4 else int(rng.integers(2, 7))
         big = (sigma == 4 and k >= 11) or (sigma == 20 and k >= 5)        # keep the CPU oracle's share small
