@@ -539,6 +539,7 @@ template <int SIGMA, int K> constexpr int quad_tw() { return K <= 10 ? IPK_QTW :
 #define IPK_QROWLANE 0
 #endif
 template <int SIGMA, int K> constexpr bool quad_rowlane() { return K <= 10 ? IPK_QROWLANE != 0 : IPK_QROWLANE12 != 0; }
+inline bool quad_rowlane_rt(uint32_t sigma, uint32_t k) { return sigma == 4 && (k <= 10 ? IPK_QROWLANE != 0 : IPK_QROWLANE12 != 0); }
 template <int SIGMA, int K> size_t quad_lds()
 {
     if constexpr (!quad_ok<SIGMA, K>()) return 0;
@@ -972,7 +973,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     sp.gm_off = ctx->gm.as<uint32_t>(); sp.gm_list = ctx->gm.as<uint32_t>() + gb + 1;
     sp.sites = pl.sites; sp.nwin = pl.nwin; sp.tiles_per_mat = tiles_per_mat; sp.S = S;
     sp.eps = pl.eps;
-    sp.pool = nullptr; sp.pool_cap = 0; sp.pool_next = nullptr; sp.desc = nullptr; sp.pool_ovf = nullptr;
+    sp.pool = nullptr; sp.pool_cap = 0; sp.pool_next = nullptr; sp.desc = nullptr; sp.pool_ovf = nullptr; sp.pre_chunks = 0;
     sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot;
     sp.flags = 0;
     xp.cnt = ctx->gbcnt.as<uint32_t>();
@@ -1171,7 +1172,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         ss.sites = pl.sites; ss.nwin = pl.nwin; ss.tiles_per_mat = s_tiles_per_mat;
         ss.S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(s_tiles_per_mat, (uint64_t)ctx->num_cu * 4 / n_s));
         ss.eps = pl.eps;
-        ss.pool = nullptr; ss.pool_cap = 0; ss.pool_next = nullptr; ss.desc = nullptr; ss.pool_ovf = nullptr;
+        ss.pool = nullptr; ss.pool_cap = 0; ss.pool_next = nullptr; ss.desc = nullptr; ss.pool_ovf = nullptr; ss.pre_chunks = 0;
         ss.emitted = p.emitted; ss.ovf_queue = p.ovf_queue; ss.ovf_count = p.ovf_count; ss.mat_slot = p.mat_slot;
         ss.flags = 2u;
         if (use_quad) RC_TRY(dispatch_quad_pass1(ctx, pl.sigma, pl.k, ss, n_s * ss.S, true));
@@ -1246,7 +1247,14 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         RC_TRY(ensure(ctx, ctx->gboff, (n_gb + 1) * 8));
         uint32_t* d_pool_next = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 32);
         uint32_t* d_pool_ovf = d_pool_next + 1;
+        // (row-per-lane quad kernel: the wavefronts' first chunks are handed out by position, the counter starts behind them)
+        // (the candidate-per-lane kernel stores through 32-bit offsets from a base chunk, at first the wavefront's own pre-assigned
+        //  chunks; in a pool beyond 4 GiB the first chunk it DRAWS lies outside that window and the wavefront rebases once -- by then
+        //  its buckets have filled most of their first chunks without a single roll; debug_flags bit 5 switches the hand-out off)
+        const bool pre_ok = use_quad && n_waves * NBK + 1024 <= cap && !(ctx->opt_flags & 32);
+        const uint32_t pre_chunks = pre_ok ? (uint32_t)(n_waves * NBK) : 0u;
         HIP_TRY(ctx, hipMemsetAsync(d_pool_next, 0, 8, ctx->stream));
+        if (pre_chunks) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_pool_next, (int)pre_chunks, 1, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->desc.p, 0, cap * 8, ctx->stream));   // ids drawn but never opened stay empty
         HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(p.emitted, 0, 8, ctx->stream));      // a retry must not double count
@@ -1260,6 +1268,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         sp.desc = ctx->desc.as<unsigned long long>(); sp.pool_ovf = d_pool_ovf;
         sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot;
         sp.flags = (uint32_t)(ctx->opt_flags);
+        sp.pre_chunks = pre_chunks;
         Stopwatch sw(ctx->stream);
         const int ev_a = sw.mark();
         if (use_quad) RC_TRY(dispatch_quad_pass1(ctx, pl.sigma, pl.k, sp, n_wg));

@@ -325,6 +325,8 @@ struct StreamParams {
     const uint32_t* mat_slot;      // [n_mats] group slot of a matrix inside the batch (big-list kernel)
     uint32_t flags;                // diagnostics: bit 0 = skip the pool stores, bit 1 = skip the append bookkeeping too,
                                    // bit 2 = list building only, bit 3 = quad kernel rebases its store window every 8 chunks
+    uint32_t pre_chunks;           // row-per-lane quad kernel: chunks [0, pre_chunks) are handed out by position -- wavefront w's bucket b
+                                   // starts in chunk w * NB + b -- and pool_next starts at pre_chunks (0: every first chunk is drawn)
 };
 
 // M with floor(t / n) == (t * M) >> 16 for 0 <= t < 128, 1 <= n <= 64   (M = ceil(65536 / n))
