@@ -1116,13 +1116,13 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     // per group to write and read back); variant 6 forces it for any stream (sigma, k), variant 7 forces dense tables.  The big-list
     // windows then always go through the pool (the atomic kernel needs dense tables), which bounds the field widths of their queue.
     const bool pool_ovf_ok = gb < (1u << 22) && n_mats < (1u << 21) && pl.nwin < (1u << 21);
-    const bool s_compress = use_stream && pool_ovf_ok && ctx->opt_variant != 7 && ctx->opt_variant != 2 &&
-                            (ctx->opt_variant == 6 || (ctx->opt_variant == 0 && stream_tbl_value(pl.sigma, pl.k) == 32768u && pl.sigma == 4));
+    bool s_compress = use_stream && pool_ovf_ok && ctx->opt_variant != 7 && ctx->opt_variant != 2 &&
+                      (ctx->opt_variant == 6 || (ctx->opt_variant == 0 && stream_tbl_value(pl.sigma, pl.k) == 32768u && pl.sigma == 4));
     ctx->comp_own_vals = false;
     const uint32_t SNW = use_quad ? quad_waves(pl.sigma, pl.k) : stream_waves(pl.sigma, pl.k);
     const uint32_t STW = use_quad ? quad_tile(pl.sigma, pl.k) : stream_tile(pl.sigma, pl.k);
     const uint32_t s_tiles_per_mat = (pl.nwin + STW - 1) / STW;
-    if (!xp_compress && !s_compress) {
+    if (!use_stream && !xp_compress) {                     // (the stream variant decides its table form below, once the pair rate is known)
         RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 4));
         p.table = ctx->table.p;
     }
@@ -1189,6 +1189,16 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
     }
     const double ppw_est = ctx->pairs_per_window > 0 ? ctx->pairs_per_window : 256.0;
+    // ... and wherever the groups are small next to the key space: short alignments (cfg5's D652-like shape: 2 x 1391 windows x 133 pairs
+    // per group against 4^10 slots, a third of them ever touched) leave dense tables mostly empty, and the reduce would write and the
+    // key-major writer read 4 MB per group for 1.4 MB of scores
+    if (!s_compress && use_stream && pool_ovf_ok && ctx->opt_variant == 0 && pl.table_size >= (1u << 16) &&
+        (double)windows * ppw_est < 0.5 * (double)gb * (double)pl.table_size)
+        s_compress = true;
+    if (!s_compress) {
+        RC_TRY(ensure(ctx, ctx->table, (size_t)gb * pl.table_size * 4));
+        p.table = ctx->table.p;
+    }
     const size_t lds_bytes = use_quad ? quad_lds_bytes(pl.sigma, pl.k) : stream_lds_bytes(pl.sigma, pl.k);
     const uint64_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(32 / SNW, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
     const uint64_t slots = (uint64_t)ctx->num_cu * wg_per_cu;
