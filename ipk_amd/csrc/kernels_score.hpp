@@ -929,6 +929,53 @@ __device__ __forceinline__ void xp_rank_by_counting(uint32_t n, const unsigned l
     }
 }
 
+// Bitonic sort, descending, of NCH * 64 64-bit keys held one per (register c, lane): element e = c * 64 + lane; afterwards
+// kj[c] of lane l is the key of rank c * 64 + l.  Strides below 64 exchange across lanes (ds_bpermute), strides of 64 and more
+// between a lane's own registers.  Keys are distinct (the position is part of them), padding keys are 0 and end up last.
+// n = 135 (the mean at AA k=6, four registers): 33 lane stages of 4 x ~7 instructions + 3 register stages against 135 x (2 readlanes
+// + 3 64-bit compares) for ranking by counting -- and no O(n^2).
+template <int NCH, int RC>
+__device__ __forceinline__ void xp_sort_desc(unsigned long long (&kj)[RC])
+{
+    static_assert(NCH >= 1 && NCH <= RC && (NCH & (NCH - 1)) == 0, "a power of two of 64-key registers");
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int size = 2; size <= NCH * 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            if (stride >= 64) {
+                constexpr int dummy = 0; (void)dummy;
+                const int cs = stride >> 6;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if ((c & cs) != 0) continue;
+                    // block of `size` elements this pair lies in: descending where (e & size) == 0  (e's lane bits do not reach size >= 128)
+                    const bool desc = ((c * 64) & size) == 0 || size == NCH * 64;
+                    const unsigned long long a = kj[c], b = kj[c | cs];
+                    const bool sw = desc ? (a < b) : (a > b);
+                    kj[c] = sw ? b : a;
+                    kj[c | cs] = sw ? a : b;
+                }
+            } else {
+                const int addr = (int)((lane ^ (uint32_t)stride) << 2);
+                const bool lower = (lane & (uint32_t)stride) == 0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const unsigned long long a = kj[c];
+                    const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)a);
+                    const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(a >> 32));
+                    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+                    const uint32_t e = (uint32_t)c * 64u + lane;
+                    const bool desc = (e & (uint32_t)size) == 0 || size == NCH * 64;
+                    const bool keep_max = lower == desc;                 // the lower index of a descending pair keeps the larger key
+                    const bool take = keep_max ? (o > a) : (o < a);
+                    kj[c] = take ? o : a;
+                }
+            }
+        }
+    }
+}
+
 struct XpParams {
     StreamParams s;                // pool_next / desc / pool_ovf unused
     uint32_t* cnt;                 // [(group * NB + bucket) * stride + segment]   (count pass output)
@@ -1038,37 +1085,35 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
             uint32_t rx[RC];
             float ry[RC];
             if constexpr (WRITE) {
-                unsigned long long kj[RC];
-                uint32_t rank[RC], ryb[RC];
+                constexpr int RCP = RC <= 1 ? 1 : RC <= 2 ? 2 : RC <= 4 ? 4 : RC <= 8 ? 8 : 16;      // registers of the sorting network: a power of two
+                static_assert(RC <= 16, "half lists of at most 1024 entries on the fast path");
+                unsigned long long kj[RCP];
+#pragma unroll
+                for (int ch = 0; ch < RCP; ++ch) {
+                    const uint32_t j = (uint32_t)ch * 64 + lane;
+                    kj[ch] = 0;
+                    if (ch < RC && j < nR) kj[ch] = ((unsigned long long)enc_score_bits(R[j].y) << 32) | (unsigned long long)(0xFFFFFFFFu - j);
+                }
+                // (score, position) keys sorted in registers (bitonic network over as many 64-key registers as the list needs)
+                const uint32_t nch = (nR + 63) >> 6;
+                if (nch <= 1) xp_sort_desc<1, RCP>(kj);
+                else if (nch <= 2) { if constexpr (RCP >= 2) xp_sort_desc<2, RCP>(kj); }
+                else if (nch <= 4) { if constexpr (RCP >= 4) xp_sort_desc<4, RCP>(kj); }
+                else if (nch <= 8) { if constexpr (RCP >= 8) xp_sort_desc<8, RCP>(kj); }
+                else { if constexpr (RCP >= 16) xp_sort_desc<16, RCP>(kj); }
+                // the entry of rank e comes from position j = ~key.low of the unsorted list: gathered, then written back in order
+                uint32_t ryb[RC];
 #pragma unroll
                 for (int ch = 0; ch < RC; ++ch) {
-                    const uint32_t j = (uint32_t)ch * 64 + lane;
-                    rx[ch] = 0; ryb[ch] = 0; kj[ch] = 0; rank[ch] = 0;
-                    if (j < nR) {
-                        const uint2 b = R[j];
-                        rx[ch] = b.x; ryb[ch] = b.y;
-                        kj[ch] = ((unsigned long long)enc_score_bits(b.y) << 32) | (unsigned long long)(0xFFFFFFFFu - j);
-                    }
-                }
-                switch ((nR + 63) >> 6) {
-                    case 1: xp_rank_by_counting<1, RC>(nR, kj, rank); break;
-                    case 2: if constexpr (RC >= 2) xp_rank_by_counting<2, RC>(nR, kj, rank); break;
-                    case 3: if constexpr (RC >= 3) xp_rank_by_counting<3, RC>(nR, kj, rank); break;
-                    case 4: if constexpr (RC >= 4) xp_rank_by_counting<4, RC>(nR, kj, rank); break;
-                    default: xp_rank_by_counting<RC, RC>(nR, kj, rank); break;
+                    const uint32_t e = (uint32_t)ch * 64 + lane;
+                    rx[ch] = 0; ryb[ch] = 0; ry[ch] = 0.f;
+                    if (e < nR) { const uint2 b = R[0xFFFFFFFFu - (uint32_t)kj[ch]]; rx[ch] = b.x; ryb[ch] = b.y; ry[ch] = __uint_as_float(b.y); }
                 }
                 wave_lds_sync();                           // every lane has read the unsorted list
 #pragma unroll
                 for (int ch = 0; ch < RC; ++ch)
-                    if ((uint32_t)ch * 64 + lane < nR) Rs[rank[ch]] = make_uint2(rx[ch], ryb[ch]);
+                    if ((uint32_t)ch * 64 + lane < nR) Rs[(uint32_t)ch * 64 + lane] = make_uint2(rx[ch], ryb[ch]);
                 wave_lds_sync();
-                // the sorted list in registers: lane l holds Rs[l], Rs[l + 64], ...
-#pragma unroll
-                for (int ch = 0; ch < RC; ++ch) {
-                    const uint32_t j = (uint32_t)ch * 64 + lane;
-                    rx[ch] = 0; ry[ch] = 0.f;
-                    if (j < nR) { const uint2 b = Rs[j]; rx[ch] = b.x; ry[ch] = __uint_as_float(b.y); }
-                }
             }
             const uint32_t P2 = 1u << (31 - __builtin_clz(nR));                // largest power of two <= nR
             for (uint32_t ib = 0; ib < nL; ib += 64) {
