@@ -365,15 +365,18 @@ constexpr int NW = 8;    // wavefronts per workgroup
 #ifndef IPK_AACAP
 #define IPK_AACAP 512
 #endif
+// DNA k = 11, 12 (row-per-lane join, one window's child nodes at a time): a wavefront needs 2 KB of child lists, 2 x 384 half-list
+// entries and 4 KB of bucket words = 12 KB; three workgroups of FOUR wavefronts with 32-window tiles fit a CU = 12 wavefronts
+// (round 2: capacity 416, 64-window tiles, three workgroups of three = 9).  cfg3 share, scoring kernel: 6.15 ms at 9 wavefronts,
+// 5.58 ms at 12; capacity 352 / 320 trade the same occupancy for more big-list windows (step 15.0 / 15.1 ms against 14.6).
 #ifndef IPK_QCAP12
-#define IPK_QCAP12 416      // DNA k = 11, 12: the largest half-list capacity that leaves three 3-wavefront workgroups per CU (512: two; cfg3 share 18.6 ms
-                            // against 19.1 at 320 -- fewer big-list windows -- and 21.8 with the round-1 shape of one 7-wavefront workgroup at 512)
+#define IPK_QCAP12 384
 #endif
 #ifndef IPK_QNW12
-#define IPK_QNW12 3        // with 64-window tiles: three workgroups of three wavefronts per CU (cfg3 share: scoring 9.0 ms against 10.3 with one of eight)
+#define IPK_QNW12 4
 #endif
 #ifndef IPK_QTW12
-#define IPK_QTW12 64
+#define IPK_QTW12 32
 #endif
 template <int SIGMA, int K> constexpr int fast_cap()
 {
@@ -540,6 +543,11 @@ template <int SIGMA, int K> constexpr int quad_tw() { return K <= 10 ? IPK_QTW :
 #endif
 template <int SIGMA, int K> constexpr bool quad_rowlane() { return K <= 10 ? IPK_QROWLANE != 0 : IPK_QROWLANE12 != 0; }
 inline bool quad_rowlane_rt(uint32_t sigma, uint32_t k) { return sigma == 4 && (k <= 10 ? IPK_QROWLANE != 0 : IPK_QROWLANE12 != 0); }
+// child nodes of one window per wavefront step (kernels_quad.hpp, ONEWIN): k = 11, 12
+#ifndef IPK_QONEWIN12
+#define IPK_QONEWIN12 1
+#endif
+template <int SIGMA, int K> constexpr bool quad_onewin() { return K >= 11 && IPK_QONEWIN12 != 0 && quad_rowlane<SIGMA, K>(); }
 template <int SIGMA, int K> size_t quad_lds()
 {
     if constexpr (!quad_ok<SIGMA, K>()) return 0;
@@ -547,7 +555,7 @@ template <int SIGMA, int K> size_t quad_lds()
         constexpr int CAP = fast_cap<SIGMA, K>();
         constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
-        return QuadTile<SIGMA, K, quad_tw<SIGMA, K>()>::HEAD_BYTES + (size_t)quad_nw<SIGMA, K>() * quad_wave_entries<SIGMA, K, CAP>() * 8 +
+        return QuadTile<SIGMA, K, quad_tw<SIGMA, K>()>::HEAD_BYTES + (size_t)quad_nw<SIGMA, K>() * quad_wave_entries<SIGMA, K, CAP, quad_onewin<SIGMA, K>()>() * 8 +
                (size_t)quad_nw<SIGMA, K>() * NB * 8;
     }
 }
@@ -560,7 +568,7 @@ int launch_quad_pass1(ipkgpu_ctx* ctx, const StreamParams& sp, uint32_t n_wg)
         constexpr uint32_t TBL = stream_tbl<SIGMA, K>();
         constexpr int QNW = quad_nw<SIGMA, K>(), QTW = quad_tw<SIGMA, K>();
         const size_t lds = quad_lds<SIGMA, K>();
-        auto kern = score_quad_kernel<SIGMA, K, CAP, QTW, QNW, TBL, COUNT_ONLY, quad_rowlane<SIGMA, K>()>;
+        auto kern = score_quad_kernel<SIGMA, K, CAP, QTW, QNW, TBL, COUNT_ONLY, quad_rowlane<SIGMA, K>(), quad_onewin<SIGMA, K>()>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(QNW * 64), lds, ctx->stream, sp);

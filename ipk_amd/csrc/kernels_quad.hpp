@@ -61,6 +61,13 @@ struct QuadGeo {
     }
     static constexpr int step_of(int n) { for (int s = 0; s < NSTEPS; ++s) if (step(s).A == n || step(s).B == n) return s; return -1; }
     static constexpr int slot_of(int n) { return step(step_of(n)).B == n ? 1 : 0; }
+    // ONE window per wavefront step (k = 11, 12: half the child-list scratch): the four 16-lane slots hold up to four nodes of equal
+    // size of the same window -- the 2-symbol nodes in one step, the 3-symbol nodes in another
+    static constexpr int NS1 = (count_h(2) > 0 ? 1 : 0) + (count_h(3) > 0 ? 1 : 0);
+    static constexpr int step1_h(int s) { return (s == 0 && count_h(2) > 0) ? 2 : 3; }
+    static constexpr int step1_node(int s, int slot) { return nth_h(step1_h(s), slot); }        // -1: the slot idles
+    static constexpr int step1_of(int n) { return node(n).H == 2 ? 0 : (count_h(2) > 0 ? 1 : 0); }
+    static constexpr int slot1_of(int n) { int c = 0; for (int m = 0; m < n; ++m) c += node(m).H == node(n).H; return c; }
 };
 
 template <int SIGMA, int K, int TW>
@@ -72,11 +79,11 @@ struct QuadTile {
     static constexpr int HEAD_BYTES = (COLS_F + BEST_F + TH_FLOATS) * 4;
 };
 
-template <int SIGMA, int K, int CAP>
+template <int SIGMA, int K, int CAP, bool ONEWIN = false>
 constexpr uint32_t quad_wave_entries()
 {
     using Q = QuadGeo<SIGMA, K>;
-    return 2 * Q::CW + Geo<SIGMA, Q::HL, CAP>::CAPH + Geo<SIGMA, Q::HR, CAP>::CAPH;
+    return (ONEWIN ? 1 : 2) * Q::CW + Geo<SIGMA, Q::HL, CAP>::CAPH + Geo<SIGMA, Q::HR, CAP>::CAPH;
 }
 
 // Thresholds of one node (J, H) under the node threshold e (Direct<>::eval's own expressions, dcla_device.hpp).
@@ -369,7 +376,12 @@ __device__ __forceinline__ void store_pair_if_gt(unsigned long long& cursor, uin
 // add + compare + add-with-carry per column counts the row's passing pairs (pass 1); every row reserves its run with one
 // LDS atomic (one round trip per (row block, column block), not per step); pass 2 walks the columns again and the passing
 // lanes store to their run, `row pointer + 8 * pairs so far`.  Same float operations, same pairs (pk_compute.cpp:90-91).
-template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL, bool COUNT_ONLY = false, bool ROWLANE = false>
+//
+// ONEWIN (k = 11, 12, with ROWLANE): the child nodes of ONE window per wavefront step, its four nodes in the four 16-lane slots,
+// instead of two nodes of two windows: the same number of steps per window at k = 12 (all four nodes have three symbols), but
+// only one window's child lists are alive at a time -- 2 KB less LDS per wavefront, which with 32-window tiles and half-list
+// capacity 384 admits a fourth workgroup per CU (12 wavefronts instead of 9).
+template <int SIGMA, int K, int CAP, int TW, int NW, uint32_t TBL, bool COUNT_ONLY = false, bool ROWLANE = false, bool ONEWIN = false>
 __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -382,7 +394,9 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
     constexpr uint32_t mulR = Q::mulR;
     static_assert(TBL % mulR == 0, "a row of the final join must stay inside one bucket");
     constexpr uint32_t CAPL = Geo<SIGMA, Q::HL, CAP>::CAPH, CAPR = Geo<SIGMA, Q::HR, CAP>::CAPH;
-    constexpr uint32_t WS = quad_wave_entries<SIGMA, K, CAP>();
+    constexpr uint32_t WS = quad_wave_entries<SIGMA, K, CAP, ONEWIN>();
+    constexpr uint32_t WPW = ONEWIN ? 1u : 2u;                     // windows per wavefront step
+    constexpr int NST = ONEWIN ? Q::NS1 : Q::NSTEPS;
     float* cols = reinterpret_cast<float*>(smem);
     float* best = cols + QT::COLS_F;
     float* thr = best + QT::BEST_F;
@@ -397,8 +411,8 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
     const uint32_t t_lo = (uint32_t)(((uint64_t)total_tiles * seg) / p.S);
     const uint32_t t_hi = (uint32_t)(((uint64_t)total_tiles * (seg + 1)) / p.S);
 
-    uint2* child = scratch_all + (size_t)wave * WS;                // [2][CW]
-    uint2* lp = child + 2 * Q::CW;                                 // L list (codes already multiplied by mulR)
+    uint2* child = scratch_all + (size_t)wave * WS;                // [WPW][CW]
+    uint2* lp = child + WPW * Q::CW;                               // L list (codes already multiplied by mulR)
     uint2* rp = lp + CAPL;                                         // R list
     using Appender = std::conditional_t<ROWLANE, LaneAppender<NB, CH>, RowAppender<NB, CH>>;
     Appender app{p, state_all + (size_t)wave * NB, g};
@@ -406,25 +420,37 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
     unsigned long long emitted = 0;
 
     // lane roles: slot = lane / 16 = (window half, node slot of the step), 16 candidates per slot
-    const uint32_t l16 = lane & 15u, slot = lane >> 4, half = lane >> 5, sb = slot & 1u;
+    const uint32_t l16 = lane & 15u, slot = lane >> 4, half = ONEWIN ? 0u : lane >> 5, sb = slot & 1u;
     const uint32_t lt16 = (1u << l16) - 1u;
     const float lane_h = (float)lane + 0.5f;
     const float eps = p.eps;
     constexpr bool count_only = COUNT_ONLY;
     // per step: the node this lane's slot evaluates
-    uint32_t st_j4[Q::NSTEPS], st_th[Q::NSTEPS], st_off[Q::NSTEPS], st_cmul[Q::NSTEPS], st_code[Q::NSTEPS];
-    bool st_on[Q::NSTEPS];
+    uint32_t st_j4[NST], st_th[NST], st_off[NST], st_cmul[NST], st_code[NST];
+    bool st_on[NST];
 #pragma unroll
-    for (int s = 0; s < Q::NSTEPS; ++s) {
+    for (int s = 0; s < NST; ++s) {
         constexpr QuadNode none{0, 2, 0, 0, 0, 1u};
-        const QuadStep qs = Q::step(s);
-        const QuadNode na = Q::node(qs.A), nb = qs.B >= 0 ? Q::node(qs.B) : none;
-        st_j4[s] = sb ? (uint32_t)nb.J * 4u : (uint32_t)na.J * 4u;
-        st_th[s] = sb ? (uint32_t)nb.TH : (uint32_t)na.TH;
-        st_off[s] = (sb ? (uint32_t)nb.OFF : (uint32_t)na.OFF) + half * Q::CW;
-        st_cmul[s] = sb ? nb.CMUL : na.CMUL;
-        st_code[s] = l16 * st_cmul[s];
-        st_on[s] = sb ? qs.B >= 0 : true;
+        if constexpr (ONEWIN) {
+            QuadNode nd = none;
+            bool on = false;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int n = Q::step1_node(s, sl);
+                if (n >= 0 && slot == (uint32_t)sl) { nd = Q::node(n); on = true; }
+            }
+            st_j4[s] = (uint32_t)nd.J * 4u; st_th[s] = (uint32_t)nd.TH; st_off[s] = (uint32_t)nd.OFF; st_cmul[s] = nd.CMUL;
+            st_code[s] = l16 * st_cmul[s]; st_on[s] = on;
+        } else {
+            const QuadStep qs = Q::step(s);
+            const QuadNode na = Q::node(qs.A), nb = qs.B >= 0 ? Q::node(qs.B) : none;
+            st_j4[s] = sb ? (uint32_t)nb.J * 4u : (uint32_t)na.J * 4u;
+            st_th[s] = sb ? (uint32_t)nb.TH : (uint32_t)na.TH;
+            st_off[s] = (sb ? (uint32_t)nb.OFF : (uint32_t)na.OFF) + half * Q::CW;
+            st_cmul[s] = sb ? nb.CMUL : na.CMUL;
+            st_code[s] = l16 * st_cmul[s];
+            st_on[s] = sb ? qs.B >= 0 : true;
+        }
     }
 
     for (uint32_t t = t_lo; t < t_hi; ++t) {
@@ -457,37 +483,43 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
         }
         __syncthreads();
 
-        const uint32_t npair = (nw + 1) / 2;
-        const float* thw = thr + __umul24(wave * 2u + half, (uint32_t)Q::TH_F);     // this lane's window's thresholds: advanced, not recomputed
-        for (uint32_t pr = wave; pr < npair; pr += NW, thw += 2 * NW * Q::TH_F) {
-            const uint32_t wq = pr * 2;
+        const uint32_t npair = (nw + WPW - 1) / WPW;
+        const float* thw = thr + __umul24(wave * WPW + half, (uint32_t)Q::TH_F);    // this lane's window's thresholds: advanced, not recomputed
+        for (uint32_t pr = wave; pr < npair; pr += NW, thw += WPW * NW * Q::TH_F) {
+            const uint32_t wq = pr * WPW;
             const uint32_t wl = wq + half;                                       // this lane's window
             const bool wvalid = wl < nw;
             uint32_t counts[3] = {0, 0, 0};                                      // per step: list length of this lane's slot
             wave_lds_sync();                                                     // the previous pair's lists are consumed
             auto run_step = [&](auto S) {
                 constexpr int s = decltype(S)::value;
-                if constexpr (s < Q::NSTEPS) {
+                if constexpr (s < NST) {
                     const bool valid = wvalid && st_on[s];
                     const uint64_t vmask = ballot64(valid);
                     const uint32_t base = wl * 4 + st_j4[s];
-                    quad_step<Q::step(s).H>(cols, base, valid, vmask, thw + st_th[s], child + st_off[s], l16, slot, lt16, st_code[s], st_cmul[s], counts[s]);
+                    constexpr int H = ONEWIN ? Q::step1_h(s) : Q::step(s < Q::NSTEPS ? s : 0).H;
+                    quad_step<H>(cols, base, valid, vmask, thw + st_th[s], child + st_off[s], l16, slot, lt16, st_code[s], st_cmul[s], counts[s]);
                 }
             };
             run_step(std::integral_constant<int, 0>{});
             run_step(std::integral_constant<int, 1>{});
             run_step(std::integral_constant<int, 2>{});
             wave_lds_sync();
-            const uint32_t nwp = min(2u, nw - wq);
+            const uint32_t nwp = min(WPW, nw - wq);
 
 #pragma unroll 1
             for (uint32_t gw = 0; gw < nwp; ++gw) {
                 const uint32_t w = wq + gw;
                 // list lengths: lane (window gw, node slot) * 16 holds them
-                const uint32_t nla = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(0)], (int)(gw * 32 + Q::slot_of(0) * 16));
-                const uint32_t nlb = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(1)], (int)(gw * 32 + Q::slot_of(1) * 16));
-                const uint32_t nra = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(2)], (int)(gw * 32 + Q::slot_of(2) * 16));
-                const uint32_t nrb = (uint32_t)__builtin_amdgcn_readlane((int)counts[Q::step_of(3)], (int)(gw * 32 + Q::slot_of(3) * 16));
+                constexpr int so0 = ONEWIN ? Q::step1_of(0) : Q::step_of(0), so1 = ONEWIN ? Q::step1_of(1) : Q::step_of(1);
+                constexpr int so2 = ONEWIN ? Q::step1_of(2) : Q::step_of(2), so3 = ONEWIN ? Q::step1_of(3) : Q::step_of(3);
+                constexpr int sl0 = ONEWIN ? Q::slot1_of(0) : Q::slot_of(0), sl1 = ONEWIN ? Q::slot1_of(1) : Q::slot_of(1);
+                constexpr int sl2 = ONEWIN ? Q::slot1_of(2) : Q::slot_of(2), sl3 = ONEWIN ? Q::slot1_of(3) : Q::slot_of(3);
+                const uint32_t wbase = ONEWIN ? 0u : gw * 32u;
+                const uint32_t nla = (uint32_t)__builtin_amdgcn_readlane((int)counts[so0], (int)(wbase + sl0 * 16));
+                const uint32_t nlb = (uint32_t)__builtin_amdgcn_readlane((int)counts[so1], (int)(wbase + sl1 * 16));
+                const uint32_t nra = (uint32_t)__builtin_amdgcn_readlane((int)counts[so2], (int)(wbase + sl2 * 16));
+                const uint32_t nrb = (uint32_t)__builtin_amdgcn_readlane((int)counts[so3], (int)(wbase + sl3 * 16));
                 if (nla * nlb * nra * nrb == 0) continue;                        // an empty half: nothing survives  (each <= 64)
                 const uint2* cw = child + gw * Q::CW;
                 const uint2 *la = cw + Q::node(0).OFF, *lb = cw + Q::node(1).OFF, *ra = cw + Q::node(2).OFF, *rb = cw + Q::node(3).OFF;
