@@ -323,8 +323,10 @@ struct StreamParams {
     unsigned long long* ovf_queue;
     uint32_t* ovf_count;
     const uint32_t* mat_slot;      // [n_mats] group slot of a matrix inside the batch (big-list kernel)
-    uint32_t flags;                // diagnostics: bit 0 = skip the pool stores, bit 1 = skip the append bookkeeping too,
-                                   // bit 2 = list building only, bit 3 = quad kernel rebases its store window every 8 chunks
+    uint32_t flags;                // diagnostics (timing experiments and tests; results are wrong with bits 0, 1, 2, 4 set):
+                                   // bit 0 = skip the pool stores, bit 1 = skip the append bookkeeping too (row-per-lane join: no store pass),
+                                   // bit 2 = list building only, bit 3 = quad kernel rebases its store window every 8 chunks (tests),
+                                   // bit 4 = row-per-lane join: count pass only; (host) bit 5 = no first chunks by position
     uint32_t pre_chunks;           // row-per-lane quad kernel: chunks [0, pre_chunks) are handed out by position -- wavefront w's bucket b
                                    // starts in chunk w * NB + b -- and pool_next starts at pre_chunks (0: every first chunk is drawn)
 };
