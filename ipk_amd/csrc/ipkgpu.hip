@@ -27,6 +27,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <memory>
 #include <vector>
 
 #include "../../include/ipkgpu.h"
@@ -51,6 +52,40 @@ struct DevBuf {                       // grow-only device workspace
     void* p = nullptr;
     size_t cap = 0;
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// events on a stream, read after a wait
+// (events are recycled through a small per-context pool: creating and destroying a dozen of them cost 20 us of every call)
+struct EventPool {
+    std::vector<hipEvent_t> free_ev;
+    hipEvent_t get()
+    {
+        if (!free_ev.empty()) { hipEvent_t e = free_ev.back(); free_ev.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
+    void put(hipEvent_t e) { if (free_ev.size() < 64) free_ev.push_back(e); else (void)hipEventDestroy(e); }
+};
+struct Stopwatch {
+    hipStream_t stream;
+    EventPool* pool;                  // the context's (events belong to its device)
+    std::vector<hipEvent_t> ev;
+    Stopwatch(hipStream_t s, EventPool* p) : stream(s), pool(p) {}
+    ~Stopwatch() { for (hipEvent_t e : ev) pool->put(e); }
+    int mark()
+    {
+        hipEvent_t e = pool->get();
+        if (!e) return -1;
+        (void)hipEventRecord(e, stream);
+        ev.push_back(e);
+        return (int)ev.size() - 1;
+    }
+    double ms(int a, int b) const
+    {
+        float t = 0;
+        if (a < 0 || b < 0 || hipEventElapsedTime(&t, ev[a], ev[b]) != hipSuccess) return 0;
+        return t;
+    }
 };
 
 }  // namespace
@@ -97,6 +132,22 @@ struct ipkgpu_ctx {
     // up_done is recorded behind the last copy and waited for only before the staging is written again
     void* h_up = nullptr; size_t h_up_cap = 0; hipEvent_t up_done = nullptr; bool up_pending = false;
     unsigned long long emitted_host = 0; bool emitted_fetched = false;   // the batch's scored-k-mer count, read back with the batch's last wait
+    // Read-backs without a wait of their own: pinned words the stream copies into, valid after the NEXT wait on the stream.
+    // h_rb[0..15] = ctx->small (scored k-mers @0, big-list queue length @4, chunk ids drawn @8, pool-exhausted flag @9);
+    // h_rb64[RB_OWNER_OFF ..] = a key-major batch's owner offsets (RB_OWNERS_MAX + 1 of them at most).
+    uint32_t* h_rb = nullptr;
+    EventPool events;
+    // A stream-variant batch whose pool check and statistics are still owed (score_batch_finish): the call did not wait after
+    // pass 1 (spec_skip_wait: the previous call had few big-list windows -- those then take the atomic kernel whatever their number,
+    // which is always correct on dense tables) and, on request, not at its end either.
+    bool spec_skip_wait = false;
+    uint64_t pool_want_min = 0;         // chunks the pool must hold on the redo of a batch whose pool ran out
+    struct Pending {
+        bool active = false;
+        std::unique_ptr<Stopwatch> sw; int ev_a = -1, ev_b = -1, ev_c = -1, ev_d = -1;
+        uint64_t cap = 0, max_chunks = 0, windows = 0; uint32_t gb = 0; bool pool_ovf_ok = false, use_quad = false;
+    } pend;
+    uint64_t last_entries = 0; uint32_t last_gb = 0;   // the key-major writer's output of the previous batch: the next one's estimate
     double t_write_total = 0, t_write_device = 0, t_write_file = 0;   // last ipkgpu_db_write
     int num_cu = 256;
 };
@@ -126,6 +177,9 @@ struct ipkgpu_parts {
     uint2* d_entries = nullptr;               // owner-major, key-major, group order: (branch, score bits)
     std::vector<uint64_t> owner_off;          // [n_owners + 1] entry offsets
     uint64_t emitted = 0;
+    // one owner, one batch: the database's key list (the non-empty slots and their entry offsets) is built inside the scoring
+    // call, ahead of the key-major writer -- ipkgpu_db_from_parts then only hands the arrays over
+    uint32_t* pre_keys = nullptr; uint64_t* pre_key_off = nullptr; uint64_t pre_n_keys = 0; double t_keys = 0;
     double t_total = 0, t_prefix = 0, t_score = 0, t_compact = 0, t_main = 0, t_reduce = 0, t_count = 0, t_write = 0, t_km = 0;
     int score_launches = 0;
 };
@@ -153,6 +207,7 @@ struct ipkgpu_db {
 };
 
 static std::string g_create_err;
+constexpr size_t RB_BYTES = 4096, RB_OWNER_OFF = 8 /* in 64-bit words */, RB_OWNERS_MAX = 500;
 
 static int fail(ipkgpu_ctx* ctx, int code, const char* fmt, ...)
 {
@@ -242,31 +297,29 @@ static void ctx_release(ipkgpu_ctx* ctx, void* p)
     else (void)hipFree(p);
 }
 
-namespace {
-
-// Stream-ordered HIP-event stopwatch; events are destroyed with the object.
-struct Stopwatch {
-    hipStream_t stream;
-    std::vector<hipEvent_t> ev;
-    explicit Stopwatch(hipStream_t s) : stream(s) {}
-    ~Stopwatch() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
-    int mark()
-    {
-        hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return -1;
-        (void)hipEventRecord(e, stream);
-        ev.push_back(e);
-        return (int)ev.size() - 1;
+// A block of at least min_bytes, preferably want_bytes: a cached block that holds min_bytes is taken whole (*got = its size) --
+// the result buffer of the previous, equally shaped call serves the next one without a new hipMalloc.
+static hipError_t ctx_alloc_atleast(ipkgpu_ctx* ctx, void** out, size_t min_bytes, size_t want_bytes, size_t* got)
+{
+    min_bytes = std::max<size_t>((min_bytes + 255) & ~(size_t)255, 256);
+    want_bytes = std::max(want_bytes, min_bytes);
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < ctx->free_blocks.size(); ++i) {
+        const size_t cap = ctx->free_blocks[i].second;
+        if (cap >= min_bytes && cap <= want_bytes + want_bytes / 2 + (1 << 20) && (best == (size_t)-1 || cap < ctx->free_blocks[best].second)) best = i;
     }
-    double ms(int a, int b) const
-    {
-        float t = 0;
-        if (a < 0 || b < 0 || hipEventElapsedTime(&t, ev[a], ev[b]) != hipSuccess) return 0;
-        return t;
+    if (best != (size_t)-1) {
+        *out = ctx->free_blocks[best].first;
+        *got = ctx->free_blocks[best].second;
+        ctx->live_blocks[*out] = *got;
+        ctx->cached_bytes -= *got;
+        ctx->free_blocks.erase(ctx->free_blocks.begin() + best);
+        return hipSuccess;
     }
-};
-
-}  // namespace
+    const hipError_t e = ctx_alloc(ctx, out, want_bytes);
+    if (e == hipSuccess) *got = ctx->live_blocks[*out];
+    return e;
+}
 
 extern "C" {
 
@@ -310,6 +363,13 @@ int ipkgpu_create(int device_id, ipkgpu_ctx** out)
         delete ctx;
         return fail(nullptr, IPKGPU_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
     }
+    if ((e = hipHostMalloc((void**)&ctx->h_rb, RB_BYTES, hipHostMallocDefault)) != hipSuccess) {
+        (void)hipFree(ctx->small);
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return fail(nullptr, IPKGPU_ERR_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    memset(ctx->h_rb, 0, RB_BYTES);
     *out = ctx;
     return IPKGPU_OK;
 }
@@ -329,6 +389,10 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     ipkgpu_comm_release(ctx);
     if (ctx->small) (void)hipFree(ctx->small);
     if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+    ctx->pend.sw.reset();
+    for (hipEvent_t e : ctx->events.free_ev) (void)hipEventDestroy(e);
+    ctx->events.free_ev.clear();
+    if (ctx->h_rb) (void)hipHostFree(ctx->h_rb);
     if (ctx->up_done) (void)hipEventDestroy(ctx->up_done);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -888,6 +952,10 @@ namespace {
 // internal status of a scoring batch: its pair pool does not fit device memory -- the caller halves the batch and scores
 // it again (the reference's answer to "does not fit" is its on-disk mode, db_builder.cpp:673-681; here: smaller batches)
 constexpr int IPKGPU_RETRY_SMALLER = 100;
+constexpr int IPKGPU_RETRY_AGAIN = 101;                  // internal: the same batch again with a larger pair pool (stream_batch_check)
+#ifndef IPK_OVF_POOL_RATIO
+#define IPK_OVF_POOL_RATIO 500
+#endif
 
 struct Plan {
     uint32_t n_mats = 0, sites = 0, sigma = 0, k = 0;
@@ -990,7 +1058,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     xp.ovcur = ctx->gbcur.as<uint32_t>();
     xp.start = nullptr;
 
-    Stopwatch sw(ctx->stream);
+    Stopwatch sw(ctx->stream, &ctx->events);
     const int ev_a = sw.mark();
     RC_TRY(dispatch_xp(ctx, pl.sigma, pl.k, xp, gb * S, false));
     const int ev_a2 = sw.mark();
@@ -1049,9 +1117,38 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     return IPKGPU_OK;
 }
 
+// What a stream-variant batch owes after the wait that made ctx->h_rb valid: the pool's state, the statistics, the calibration of
+// the next call.  IPKGPU_RETRY_AGAIN: the pool ran out -- the batch is to be scored again (ctx->pool_want_min says how large).
+int stream_batch_check(ipkgpu_ctx* ctx)
+{
+    ipkgpu_ctx::Pending& pd = ctx->pend;
+    if (!pd.active) return IPKGPU_OK;
+    pd.active = false;
+    std::unique_ptr<Stopwatch> sw(pd.sw.release());
+    const uint32_t n_ovf = ctx->h_rb[4], pool_exhausted = ctx->h_rb[9];
+    if (pool_exhausted) {
+        if (pd.cap >= pd.max_chunks) {
+            ctx->pool_want_min = 0;
+            if (pd.gb > 1) return IPKGPU_RETRY_SMALLER;
+            return fail(ctx, IPKGPU_ERR_NOMEM, "the pair pool of ONE branch group is exhausted at the device-memory limit");
+        }
+        ctx->pool_want_min = pd.cap * 2;
+        return IPKGPU_RETRY_AGAIN;
+    }
+    ctx->pool_want_min = 0;
+    memcpy(&ctx->emitted_host, ctx->h_rb, 8);
+    ctx->emitted_fetched = true;
+    // the next call skips the wait after pass 1 if its big-list windows would take the atomic kernel anyway
+    ctx->spec_skip_wait = !(n_ovf > 0 && (uint64_t)n_ovf * IPK_OVF_POOL_RATIO >= pd.windows && pd.pool_ovf_ok);
+    if (sw) { ctx->acc_main_ms += sw->ms(pd.ev_a, pd.ev_b); ctx->acc_reduce_ms += sw->ms(pd.ev_c, pd.ev_d); }
+    return IPKGPU_OK;
+}
+
 // Scores groups [g0, g0 + gb) into ctx->table ([gb][table_size]); *emitted_out = scored phylo-k-mers of the batch.
+// defer: a stream-variant batch may return with its last wait still owed (ctx->pend.active) -- the caller waits on the stream
+// later anyway and then calls score_batch_finish.
 int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t g0, uint32_t gb,
-                     std::vector<uint32_t>& idx_host)
+                     std::vector<uint32_t>& idx_host, bool defer)
 {
     const uint32_t n_mats = pl.n_mats;
     (void)idx_host;
@@ -1105,7 +1202,6 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     p.mask = nullptr; p.mask_words = 0;
     ctx->mask_valid = false;
     ctx->table_compressed = false;
-    HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
     const uint32_t NBK = stream_buckets(pl.sigma, pl.k);
     const uint32_t XNB = xp_buckets(pl.sigma, pl.k);
     // variant 0 = default: stream where its per-wave chunk state fits (all DNA k, AA k <= 5), exact partition for
@@ -1119,6 +1215,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     // pass 1 of the stream variant: the quad kernel (kernels_quad.hpp) where it exists (DNA k = 8..12), variant 2 forces the
     // first-generation score_stream_kernel, variant 5 asks for the quad kernel explicitly
     const bool use_quad = use_stream && ctx->opt_variant != 2 && quad_supported(pl.sigma, pl.k);
+    if (!use_stream) {                                     // (the stream variant resets its counters in one launch: small_reset_kernel)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->small, 0, 8, ctx->stream));            // per-batch scored-k-mer counter
+        HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
+    }
     // The chunk-fed reduce ends in the compressed table form (occupancy bits + rank + the non-empty slots' score codes, comp_table.hpp)
     // where the scored k-mers fill the key space sparsely: DNA k = 11, 12 (cfg3: 38 % of 4^12 slots per group -- no 64 MB dense table
     // per group to write and read back); variant 6 forces it for any stream (sigma, k), variant 7 forces dense tables.  The big-list
@@ -1136,7 +1236,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     }
     if (!use_stream && !use_xp) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->table.p, 0, (size_t)gb * pl.table_size * 4, ctx->stream));
-        Stopwatch sw(ctx->stream);
+        Stopwatch sw(ctx->stream, &ctx->events);
         const int a = sw.mark();
         RC_TRY(dispatch_score(ctx, pl.sigma, pl.k, p));
         const int b = sw.mark();
@@ -1193,8 +1293,6 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         // windows that went to the big-list queue were not counted: assume they carry CAP^2 / 4 pairs each (generous)
         const double cap_pairs = 0.25 * (double)fast_cap_value(pl.sigma, pl.k) * (double)fast_cap_value(pl.sigma, pl.k);
         if (s_windows) ctx->pairs_per_window = std::max(1.0, ((double)se + (double)so * cap_pairs) / (double)s_windows * 1.15);
-        HIP_TRY(ctx, hipMemsetAsync(p.emitted, 0, 8, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
     }
     const double ppw_est = ctx->pairs_per_window > 0 ? ctx->pairs_per_window : 256.0;
     // ... and wherever the groups are small next to the key space: short alignments (cfg5's D652-like shape: 2 x 1391 windows x 133 pairs
@@ -1249,9 +1347,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         const uint64_t need = (uint64_t)((double)windows * ppw * 1.1 / CH) + (n_waves + ovf_waves) * (NBK * SUB + ALLOC_BATCH) + 1024;
         if (have >= need) want = have;
     }
+    want = std::max<uint64_t>(want, ctx->pool_want_min);           // (the redo of a batch whose pool ran out, found at a deferred check)
     for (int attempt = 0; attempt < 6; ++attempt) {
         uint64_t cap = std::min<uint64_t>(want, max_chunks);
-        const bool forced = attempt == 0 && ctx->opt_pool_chunks > 0;
+        const bool forced = attempt == 0 && ctx->opt_pool_chunks > 0 && ctx->pool_want_min == 0;
         if (forced) cap = (uint64_t)ctx->opt_pool_chunks;
         else if (cap < n_waves * NBK * SUB) {
             if (gb > 1) return IPKGPU_RETRY_SMALLER;
@@ -1260,8 +1359,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         RC_TRY(ensure(ctx, ctx->pool, (cap + 1) * CH * 8));
         RC_TRY(ensure(ctx, ctx->desc, cap * 8));
         if (!forced) cap = std::min<uint64_t>(ctx->pool.cap / (CH * 8) - 1, ctx->desc.cap / 8);
-        RC_TRY(ensure(ctx, ctx->gbcnt, n_gb * 4));
-        RC_TRY(ensure(ctx, ctx->gbcur, n_gb * 4));
+        RC_TRY(ensure(ctx, ctx->gbcnt, 2 * n_gb * 4));             // [chunks per (group, bucket) | scatter cursors]: one fill for both
+        uint32_t* const d_gbcur = ctx->gbcnt.as<uint32_t>() + n_gb;
         RC_TRY(ensure(ctx, ctx->gboff, (n_gb + 1) * 8));
         uint32_t* d_pool_next = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 32);
         uint32_t* d_pool_ovf = d_pool_next + 1;
@@ -1271,11 +1370,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         //  its buckets have filled most of their first chunks without a single roll; debug_flags bit 5 switches the hand-out off)
         const bool pre_ok = use_quad && n_waves * NBK + 1024 <= cap && !(ctx->opt_flags & 32);
         const uint32_t pre_chunks = pre_ok ? (uint32_t)(n_waves * NBK) : 0u;
-        HIP_TRY(ctx, hipMemsetAsync(d_pool_next, 0, 8, ctx->stream));
-        if (pre_chunks) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_pool_next, (int)pre_chunks, 1, ctx->stream));
+        // (one launch for the batch's counters -- a retry must not double count -- and the chunk counter's start)
+        hipLaunchKernelGGL(small_reset_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<uint32_t*>(ctx->small), pre_chunks);
+        HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemsetAsync(ctx->desc.p, 0, cap * 8, ctx->stream));   // ids drawn but never opened stay empty
-        HIP_TRY(ctx, hipMemsetAsync(p.ovf_count, 0, 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(p.emitted, 0, 8, ctx->stream));      // a retry must not double count
 
         StreamParams sp;
         sp.logp = logp_dev; sp.best = ctx->best.as<float>();
@@ -1287,7 +1385,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot;
         sp.flags = (uint32_t)(ctx->opt_flags);
         sp.pre_chunks = pre_chunks;
-        Stopwatch sw(ctx->stream);
+        std::unique_ptr<Stopwatch> sw_own(new Stopwatch(ctx->stream, &ctx->events));
+        Stopwatch& sw = *sw_own;
         const int ev_a = sw.mark();
         if (use_quad) RC_TRY(dispatch_quad_pass1(ctx, pl.sigma, pl.k, sp, n_wg));
         else RC_TRY(dispatch_stream_pass1(ctx, pl.sigma, pl.k, sp, n_wg));
@@ -1297,11 +1396,18 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         // global atomics on the finished tables after pass 2.
         // (one host round trip for the queue length and the pool's state: they are read again below only if the big-list windows
         //  go through the pool, which draws chunks too)
+        // A call that follows one with few big-list windows does not wait here at all (spec): chunk index and reduce take the
+        // number of chunks from the device, the big-list windows take the atomic kernel (always correct on dense tables; it reads
+        // the queue length itself), and the pool's state is checked with the call's last wait -- an exhausted pool then costs the
+        // redo of the reduce as well, which the calibrated pool size makes rare.
+        const bool spec = ctx->spec_skip_wait && !s_compress && !(ctx->opt_flags & 64);
         uint32_t n_ovf = 0;
         uint32_t h[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpyAsync(&n_ovf, p.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(h, d_pool_next, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (!spec) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rb, ctx->small, 64, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            n_ovf = ctx->h_rb[4]; h[0] = ctx->h_rb[8]; h[1] = ctx->h_rb[9];
+        }
         // a handful of big-list windows (< 0.2 % of the batch) are cheaper through the atomic kernel after pass 2 than
         // through sort + pool kernel; flat posteriors put a large share of the pairs there and need the pool
         const bool ovf_in_pool = n_ovf > 0 && ((uint64_t)n_ovf * IPK_OVF_POOL_RATIO >= windows || s_compress) && pool_ovf_ok;
@@ -1324,8 +1430,9 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
             RC_TRY(dispatch_stream_overflow(ctx, pl.sigma, pl.k, so));
         }
         if (ovf_in_pool) {
-            HIP_TRY(ctx, hipMemcpyAsync(h, d_pool_next, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rb, ctx->small, 64, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            h[0] = ctx->h_rb[8]; h[1] = ctx->h_rb[9];
         }
         if (h[1] != 0) {                    // pool exhausted: h[0] chunks were asked for
             if (cap >= max_chunks) {
@@ -1336,12 +1443,12 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
             want = std::max<uint64_t>(cap * 2, want);
             continue;
         }
-        const uint32_t n_used = (uint32_t)std::min<uint64_t>(h[0], cap);
+        const uint32_t n_used = spec ? (uint32_t)cap : (uint32_t)std::min<uint64_t>(h[0], cap);   // (spec: the kernels stop at the device's count)
+        const uint32_t* n_used_dev = spec ? d_pool_next : nullptr;
         // chunk index: chunk ids grouped by (group, bucket).  Unused/never-closed chunks have count 0 and are skipped;
         // descriptors of this batch's chunks were all written by pass 1 (closed or flushed), stale ones are overwritten
         // or lie beyond n_used.
-        HIP_TRY(ctx, hipMemsetAsync(ctx->gbcnt.p, 0, n_gb * 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->gbcur.p, 0, n_gb * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->gbcnt.p, 0, 2 * n_gb * 4, ctx->stream));
         RC_TRY(ensure(ctx, ctx->clist, std::max<uint64_t>(n_used, 1) * 8));
         if (s_compress) {
             RC_TRY(ensure(ctx, ctx->croom, 2 * n_gb * 4));                  // [pairs per (group, bucket) | room of its values]
@@ -1350,7 +1457,8 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         if (n_used) {
             hipLaunchKernelGGL(chunk_hist_kernel, dim3(std::min<uint32_t>((n_used + 255) / 256, 2048u)), dim3(256), 0, ctx->stream,
                                ctx->desc.as<unsigned long long>(), n_used, ctx->gbcnt.as<uint32_t>(),
-                               use_quad ? p.emitted : (unsigned long long*)nullptr, s_compress ? ctx->croom.as<uint32_t>() : (uint32_t*)nullptr);
+                               use_quad ? p.emitted : (unsigned long long*)nullptr, s_compress ? ctx->croom.as<uint32_t>() : (uint32_t*)nullptr,
+                               n_used_dev);
             HIP_TRY(ctx, hipGetLastError());
         }
         RC_TRY(scan_u32(ctx, ctx->gbcnt.as<uint32_t>(), n_gb, ctx->gboff.as<uint64_t>()));
@@ -1370,41 +1478,47 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
             RC_TRY(ensure(ctx, ctx->ucnt, n_gb * 4));
         }
         if (n_used) {
-            hipLaunchKernelGGL(chunk_scatter_kernel, dim3((n_used + 255) / 256), dim3(256), 0, ctx->stream,
-                               ctx->desc.as<unsigned long long>(), n_used, ctx->gboff.as<uint64_t>(), ctx->gbcur.as<uint32_t>(),
-                               ctx->clist.as<uint2>());
+            hipLaunchKernelGGL(chunk_scatter_kernel, dim3(std::min<uint32_t>((n_used + 255) / 256, 1u << 16)), dim3(256), 0, ctx->stream,
+                               ctx->desc.as<unsigned long long>(), n_used, ctx->gboff.as<uint64_t>(), d_gbcur,
+                               ctx->clist.as<uint2>(), n_used_dev);
             HIP_TRY(ctx, hipGetLastError());
         }
         const int ev_c = sw.mark();
         RC_TRY(dispatch_stream_pass2(ctx, pl.sigma, pl.k, (uint32_t)n_gb, pl.table_size, ctx->table.as<uint32_t>(), s_compress));
         const int ev_d = sw.mark();
-        if (n_ovf > 0 && !ovf_in_pool) RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
+        if ((spec || n_ovf > 0) && !ovf_in_pool) RC_TRY(dispatch_overflow(ctx, pl.sigma, pl.k, p));
         if (s_compress) {
             ctx->table_compressed = true; ctx->comp_own_vals = true;
             ctx->comp_nb = NBK; ctx->comp_stride = 1; ctx->comp_tbl = stream_tbl_value(pl.sigma, pl.k);
         }
-        HIP_TRY(ctx, hipMemcpyAsync(&ctx->emitted_host, p.emitted, 8, hipMemcpyDeviceToHost, ctx->stream));   // (one wait for both)
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->emitted_fetched = true;
         ctx->mask_valid = true;
-        ctx->acc_main_ms += sw.ms(ev_a, ev_b);
-        ctx->acc_reduce_ms += sw.ms(ev_c, ev_d);
         ctx->main_kernel = use_quad ? "score_quad_kernel" : "score_stream_kernel";
-        return IPKGPU_OK;
+        // the batch's counters: copied to pinned words, read at the caller's next wait (defer) or at this one
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rb, ctx->small, 64, hipMemcpyDeviceToHost, ctx->stream));
+        ipkgpu_ctx::Pending& pd = ctx->pend;
+        pd.sw.reset(sw_own.release());
+        pd.ev_a = ev_a; pd.ev_b = ev_b; pd.ev_c = ev_c; pd.ev_d = ev_d;
+        pd.cap = cap; pd.max_chunks = max_chunks; pd.windows = windows; pd.gb = gb; pd.pool_ovf_ok = pool_ovf_ok; pd.use_quad = use_quad;
+        pd.active = true;
+        if (defer) return IPKGPU_OK;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const int rcf = stream_batch_check(ctx);
+        if (rcf == IPKGPU_RETRY_AGAIN) { want = std::max<uint64_t>(want, ctx->pool_want_min); continue; }
+        return rcf;
     }
     return fail(ctx, IPKGPU_ERR_NOMEM, "pair pool could not be sized");
 }
 
-int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t g0, uint32_t gb,
-                std::vector<uint32_t>& idx_host, uint64_t* emitted_acc)
+// The part of score_batch that needs the batch's counters on the host; after a wait on the stream.  IPKGPU_RETRY_AGAIN /
+// IPKGPU_RETRY_SMALLER: the pair pool ran out (found only now, in a call that skipped the wait after pass 1) -- score the batch again.
+int score_batch_finish(ipkgpu_ctx* ctx, const Plan& pl, uint32_t g0, uint32_t gb, uint64_t* emitted_acc)
 {
-    HIP_TRY(ctx, hipMemsetAsync(ctx->small, 0, 8, ctx->stream));            // per-batch scored-k-mer counter
-    ctx->emitted_fetched = false;
-    RC_TRY(score_batch_impl(ctx, pl, logp_dev, g0, gb, idx_host));
+    if (ctx->pend.active) RC_TRY(stream_batch_check(ctx));
     unsigned long long e = ctx->emitted_host;
     if (!ctx->emitted_fetched) {
-        HIP_TRY(ctx, hipMemcpyAsync(&e, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rb, ctx->small, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(&e, ctx->h_rb, 8);
     }
     *emitted_acc += e;
     // calibration of the next call's pair pool and workgroup count: PAIRS per window (not chunks -- chunk
@@ -1415,6 +1529,17 @@ int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t
     return IPKGPU_OK;
 }
 
+// defer: the caller waits on the stream later anyway; if ctx->pend.active on return, it owes score_batch_finish after that wait
+int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t g0, uint32_t gb,
+                std::vector<uint32_t>& idx_host, uint64_t* emitted_acc, bool defer = false)
+{
+    ctx->emitted_fetched = false;
+    ctx->pend.active = false; ctx->pend.sw.reset();
+    RC_TRY(score_batch_impl(ctx, pl, logp_dev, g0, gb, idx_host, defer));
+    if (ctx->pend.active) return IPKGPU_OK;
+    return score_batch_finish(ctx, pl, g0, gb, emitted_acc);
+}
+
 // out[0..n] = exclusive scan of in[0..n)   (u32 -> u64; out[n] = the total): one single-pass device scan (rocPRIM, decoupled
 // look-back) over n + 1 items, the last one a zero -- two launches where the three-kernel scan (block sums, one workgroup over
 // the sums, apply) cost 27 us per call at a million keys, four times per scoring call.
@@ -1422,6 +1547,21 @@ struct ScanU32In {
     const uint32_t* in; uint64_t n;
     __host__ __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)in[i] : 0ull; }
 };
+struct ScanNonzeroIn {
+    const uint32_t* in; uint64_t n;
+    __host__ __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)(in[i] != 0u) : 0ull; }
+};
+// out[0..n] = exclusive scan of (in[i] != 0): the position of every non-empty slot in the key list, out[n] = the number of keys
+int scan_nonzero_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out)
+{
+    if (n == 0) { HIP_TRY(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return IPKGPU_OK; }
+    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), ScanNonzeroIn{in, n});
+    size_t bytes = 0;
+    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), ctx->stream));
+    RC_TRY(ensure(ctx, ctx->scan_sums, bytes));
+    HIP_TRY(ctx, rocprim::exclusive_scan(ctx->scan_sums.p, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), ctx->stream));
+    return IPKGPU_OK;
+}
 int scan_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out)
 {
     if (n == 0) { HIP_TRY(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return IPKGPU_OK; }
@@ -1462,7 +1602,7 @@ int ipkgpu_score_groups_device(ipkgpu_ctx* ctx, const float* logp_dev, uint32_t 
     RC_TRY(ensure(ctx, ctx->goff, (size_t)(pl.gpb + 1) * 8));
 
     ctx->acc_main_ms = ctx->acc_reduce_ms = ctx->acc_count_ms = ctx->acc_write_ms = ctx->acc_km_ms = 0;
-    Stopwatch sw(ctx->stream);
+    Stopwatch sw(ctx->stream, &ctx->events);
     const int t_begin = sw.mark();
     RC_TRY(run_prefix(ctx, pl, logp_dev));
     const int t_pre = sw.mark();
@@ -1608,7 +1748,7 @@ int ipkgpu_score_groups_positions(ipkgpu_ctx* ctx, const float* logp, uint32_t n
     RC_TRY(ensure(ctx, ctx->offsets, (size_t)(pl.gpb * cpg + 1) * 8));
     RC_TRY(ensure(ctx, ctx->goff, (size_t)(pl.gpb + 1) * 8));
     ctx->acc_main_ms = ctx->acc_reduce_ms = ctx->acc_count_ms = ctx->acc_write_ms = ctx->acc_km_ms = 0;
-    Stopwatch sw(ctx->stream);
+    Stopwatch sw(ctx->stream, &ctx->events);
     const int t_begin = sw.mark();
     RC_TRY(run_prefix(ctx, pl, d_logp));
     std::vector<uint32_t> idx_host((size_t)n_mats * 2);
@@ -1868,11 +2008,12 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     HIP_TRY(ctx, hipMemcpyAsync(ctx->branch.p, ctx->h_branch.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
 
     ctx->acc_main_ms = ctx->acc_reduce_ms = ctx->acc_count_ms = ctx->acc_write_ms = ctx->acc_km_ms = 0;
-    Stopwatch sw(ctx->stream);
+    Stopwatch sw(ctx->stream, &ctx->events);
     const int t_begin = sw.mark();
     RC_TRY(run_prefix(ctx, pl, logp_dev));
     const int t_pre = sw.mark();
     std::vector<std::pair<int, int>> ev_score, ev_compact, ev_km;
+    std::pair<int, int> ev_keys{-1, -1};
     std::vector<uint32_t> idx_host;
 
     struct Batch { uint32_t* counts = nullptr; uint2* entries = nullptr; std::vector<uint64_t> owner_off; };
@@ -1885,7 +2026,9 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     for (uint32_t g0 = 0; g0 < n_groups; g0 += gb) {
         gb = std::min<uint32_t>(gpb_now, n_groups - g0);
         const int s0 = sw.mark();
-        const int rcb = score_batch(ctx, pl, logp_dev, g0, gb, idx_host, &parts->emitted);
+        // (defer: a stream-variant batch returns without a wait of its own; what it owes -- the pool's state, the scored count --
+        //  is settled at this loop's one wait, score_batch_finish below)
+        const int rcb = score_batch(ctx, pl, logp_dev, g0, gb, idx_host, &parts->emitted, true);
         if (rcb == IPKGPU_RETRY_SMALLER) { gpb_now = std::max<uint32_t>(1, gb / 2); gb = 0; continue; }   // the batch again, half as many groups
         if (rcb) return rcb;
         const int s1 = sw.mark();
@@ -1921,47 +2064,112 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
                            ctx->offsets.as<uint64_t>(), (uint32_t)slots, P + 1, ctx->goff.as<uint64_t>());
         HIP_TRY(ctx, hipGetLastError());
         b.owner_off.resize((size_t)P + 1);
-        HIP_TRY(ctx, hipMemcpyAsync(b.owner_off.data(), ctx->goff.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.entries, std::max<uint64_t>(b.owner_off[P], 1) * 8));
-        const int km0 = sw.mark();
-        if (ctx->table_compressed) {
-            const uint64_t per_xcd = (((T + 63) / 64) + 7) / 8;
-            if (qpack)
-                KM_LAUNCH(km_write_c_kernel, KMC_CAP, comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots, b.counts,
-                          qpack, ctx->offsets.as<uint64_t>(), b.entries);
-            else if (fast_c) {
-                // more than 256 groups: passes of 256, each with its own counts; the cursors (the scan of the TOTAL counts) advance
-                // from pass to pass, so a key's entries stay in group order
-                RC_TRY(ensure(ctx, ctx->pcounts, n_slots_all * 4));
-                for (uint32_t p0 = 0; p0 < gb; p0 += 256) {
-                    const uint32_t pg = std::min<uint32_t>(256, gb - p0);
-                    const uint32_t* pmask = ctx->mask.as<uint32_t>() + (size_t)p0 * ctx->mask_words;
-                    if ((T + 31) / 32 >= (uint64_t)ctx->num_cu * 1024)
-                        hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)(((T + 31) / 32 + 255) / 256)), dim3(256), 0, ctx->stream,
-                                           pmask, ctx->mask_words, T, pg, P, slots, ctx->pcounts.as<uint32_t>(), ctx->qpack.as<uint32_t>());
-                    else
-                        hipLaunchKernelGGL(km_count_mask_key_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
-                                           pmask, ctx->mask_words, T, pg, P, slots, ctx->pcounts.as<uint32_t>(), ctx->qpack.as<uint32_t>());
-                    HIP_TRY(ctx, hipGetLastError());
-                    CompTable ctp = comp_table(ctx);
-                    ctp.mask = pmask;
-                    ctp.vaddr += (size_t)p0 * (ctx->mask_words / 2);
-                    ctp.rank += (size_t)p0 * (ctx->mask_words / 2);
-                    KM_LAUNCH(km_write_c_kernel, KMC_CAP, ctp, T, pg, ctx->branch.as<uint32_t>() + g0 + p0, P, slots, ctx->pcounts.as<uint32_t>(),
-                              ctx->qpack.as<uint32_t>(), ctx->offsets.as<uint64_t>(), b.entries);
-                    HIP_TRY(ctx, hipGetLastError());
-                }
+        const bool rb_ok = P <= RB_OWNERS_MAX;                 // (the offsets go to pinned words: a copy the stream does not stall on)
+        uint64_t* h_off = rb_ok ? reinterpret_cast<uint64_t*>(ctx->h_rb) + RB_OWNER_OFF : b.owner_off.data();
+        HIP_TRY(ctx, hipMemcpyAsync(h_off, ctx->goff.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+
+        // One owner, the whole call in one batch, a key space of moderate size: the database's key list is built here, from the counts
+        // and their scan BEFORE the writer advances it -- ipkgpu_db_from_parts would scan the counts again, in a call of its own
+        // with two more waits (a tenth of a 125-group share of cfg2).  The arrays are sized for every slot (12 bytes each).
+        const bool pre_keys = P == 1 && g0 == 0 && gb == n_groups && slots <= (1ull << 24) && rb_ok && !(ctx->opt_flags & 64);
+        uint32_t* k_keys = nullptr; uint64_t* k_off = nullptr;
+        struct KGuard { ipkgpu_ctx* c; uint32_t*& a; uint64_t*& b; ~KGuard() { ctx_release(c, a); ctx_release(c, b); } } kguard{ctx, k_keys, k_off};
+        int kt0 = -1, kt1 = -1;
+        if (pre_keys) {
+            kt0 = sw.mark();
+            RC_TRY(ensure(ctx, ctx->tmp_b, (slots + 1) * 8));
+            RC_TRY(scan_nonzero_u32(ctx, b.counts, slots, ctx->tmp_b.as<uint64_t>()));
+            HIP_TRY(ctx, hipMemcpyAsync(h_off + P + 1, ctx->tmp_b.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, ctx_alloc(ctx, (void**)&k_keys, slots * 4));
+            HIP_TRY(ctx, ctx_alloc(ctx, (void**)&k_off, (slots + 1) * 8));
+            const uint32_t nbk = (uint32_t)((slots + 1 + 255) / 256);
+            if (sigma == 4)
+                hipLaunchKernelGGL(merge_write_keys_kernel<4>, dim3(nbk), dim3(256), 0, ctx->stream, b.counts, ctx->tmp_b.as<uint64_t>(),
+                                   ctx->offsets.as<uint64_t>(), slots, 0u, 1u, (int)k, k_keys, k_off);
+            else
+                hipLaunchKernelGGL(merge_write_keys_kernel<20>, dim3(nbk), dim3(256), 0, ctx->stream, b.counts, ctx->tmp_b.as<uint64_t>(),
+                                   ctx->offsets.as<uint64_t>(), slots, 0u, 1u, (int)k, k_keys, k_off);
+            HIP_TRY(ctx, hipGetLastError());
+            kt1 = sw.mark();
+        }
+
+        // the key-major writer over `cap_e` entries of room
+        auto launch_writer = [&](uint64_t cap_e) -> int {
+            if (ctx->table_compressed) {
+                const uint64_t per_xcd = (((T + 63) / 64) + 7) / 8;
+                if (qpack)
+                    KM_LAUNCH(km_write_c_kernel, KMC_CAP, comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots, b.counts,
+                              qpack, ctx->offsets.as<uint64_t>(), b.entries, cap_e);
+                else if (fast_c) {
+                    // more than 256 groups: passes of 256, each with its own counts; the cursors (the scan of the TOTAL counts) advance
+                    // from pass to pass, so a key's entries stay in group order
+                    RC_TRY(ensure(ctx, ctx->pcounts, n_slots_all * 4));
+                    for (uint32_t p0 = 0; p0 < gb; p0 += 256) {
+                        const uint32_t pg = std::min<uint32_t>(256, gb - p0);
+                        const uint32_t* pmask = ctx->mask.as<uint32_t>() + (size_t)p0 * ctx->mask_words;
+                        if ((T + 31) / 32 >= (uint64_t)ctx->num_cu * 1024)
+                            hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)(((T + 31) / 32 + 255) / 256)), dim3(256), 0, ctx->stream,
+                                               pmask, ctx->mask_words, T, pg, P, slots, ctx->pcounts.as<uint32_t>(), ctx->qpack.as<uint32_t>());
+                        else
+                            hipLaunchKernelGGL(km_count_mask_key_kernel, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, ctx->stream,
+                                               pmask, ctx->mask_words, T, pg, P, slots, ctx->pcounts.as<uint32_t>(), ctx->qpack.as<uint32_t>());
+                        HIP_TRY(ctx, hipGetLastError());
+                        CompTable ctp = comp_table(ctx);
+                        ctp.mask = pmask;
+                        ctp.vaddr += (size_t)p0 * (ctx->mask_words / 2);
+                        ctp.rank += (size_t)p0 * (ctx->mask_words / 2);
+                        KM_LAUNCH(km_write_c_kernel, KMC_CAP, ctp, T, pg, ctx->branch.as<uint32_t>() + g0 + p0, P, slots, ctx->pcounts.as<uint32_t>(),
+                                  ctx->qpack.as<uint32_t>(), ctx->offsets.as<uint64_t>(), b.entries, cap_e);
+                        HIP_TRY(ctx, hipGetLastError());
+                    }
+                } else
+                    hipLaunchKernelGGL(km_write_c_generic_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
+                                       comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
+                                       ctx->offsets.as<uint64_t>(), b.entries, cap_e);
             } else
-                hipLaunchKernelGGL(km_write_c_generic_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
-                                   comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
-                                   ctx->offsets.as<uint64_t>(), b.entries);
-        } else
-            hipLaunchKernelGGL(km_write_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
-                               ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
-                               ctx->offsets.as<uint64_t>(), b.entries);
-        HIP_TRY(ctx, hipGetLastError());
-        const int km1 = sw.mark();
+                hipLaunchKernelGGL(km_write_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
+                                   ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
+                                   ctx->offsets.as<uint64_t>(), b.entries, cap_e);
+            HIP_TRY(ctx, hipGetLastError());
+            return IPKGPU_OK;
+        };
+        // With the previous call's entries per group as the estimate, the writer's output is allocated and the writer launched
+        // BEFORE the host knows the total: the batch's one wait then covers scoring, counting and writing.  A writer that finds
+        // less room than the total leaves everything untouched (kernels_keymajor.hpp) and runs again below, after that wait.
+        uint64_t cap_e = 0;
+        const bool spec_e = rb_ok && ctx->last_gb > 0 && ctx->last_entries > 0 && !(ctx->opt_flags & 64);
+        int km0 = -1, km1 = -1;
+        if (spec_e) {
+            const uint64_t est = (uint64_t)((unsigned __int128)ctx->last_entries * gb / ctx->last_gb);
+            size_t got = 0;
+            if (ctx_alloc_atleast(ctx, (void**)&b.entries, est * 8, (est + est / 20 + 4096) * 8, &got) == hipSuccess) cap_e = got / 8;
+            else { (void)hipGetLastError(); b.entries = nullptr; }
+        }
+        if (cap_e) { km0 = sw.mark(); RC_TRY(launch_writer(cap_e)); km1 = sw.mark(); }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));              // the batch's one wait
+        const int rcf = ctx->pend.active ? score_batch_finish(ctx, pl, g0, gb, &parts->emitted) : IPKGPU_OK;
+        if (rcf == IPKGPU_RETRY_SMALLER || rcf == IPKGPU_RETRY_AGAIN) {
+            // the pair pool ran out (a call that skipped the wait after pass 1 learns it only here): the batch again
+            ctx_release(ctx, b.counts); ctx_release(ctx, b.entries);
+            batches.pop_back();
+            ev_score.pop_back(); parts->score_launches -= 1;
+            if (rcf == IPKGPU_RETRY_SMALLER) gpb_now = std::max<uint32_t>(1, gb / 2);
+            gb = 0;
+            continue;
+        }
+        if (rcf) return rcf;
+        if (rb_ok) memcpy(b.owner_off.data(), h_off, ((size_t)P + 1) * 8);
+        if (b.owner_off[P] > cap_e || cap_e == 0) {
+            ctx_release(ctx, b.entries); b.entries = nullptr;
+            HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.entries, std::max<uint64_t>(b.owner_off[P], 1) * 8));
+            km0 = sw.mark(); RC_TRY(launch_writer(std::max<uint64_t>(b.owner_off[P], 1))); km1 = sw.mark();
+        }
+        ctx->last_entries = b.owner_off[P]; ctx->last_gb = gb;
+        if (pre_keys) {
+            parts->pre_keys = k_keys; parts->pre_key_off = k_off; parts->pre_n_keys = h_off[P + 1];
+            k_keys = nullptr; k_off = nullptr;
+            ev_keys = {kt0, kt1};
+        }
         ev_km.push_back({km0, km1});
         ev_compact.push_back({s1, km1});
     }
@@ -2005,6 +2213,7 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
     parts->t_main = ctx->acc_main_ms; parts->t_reduce = ctx->acc_reduce_ms;
     parts->t_count = ctx->acc_count_ms; parts->t_write = ctx->acc_write_ms; parts->t_km = ctx->acc_km_ms;
     for (auto& pr : ev_compact) parts->t_compact += sw.ms(pr.first, pr.second);
+    parts->t_keys = sw.ms(ev_keys.first, ev_keys.second);
     guard.r = nullptr;
     *out = parts;
     return IPKGPU_OK;
@@ -2036,7 +2245,10 @@ double ipkgpu_parts_time_ms(const ipkgpu_parts* p, int which)
 void ipkgpu_parts_free(ipkgpu_parts* p)
 {
     if (!p) return;
-    if (p->ctx) { (void)hipSetDevice(p->ctx->device); ctx_release(p->ctx, p->d_counts); ctx_release(p->ctx, p->d_entries); }
+    if (p->ctx) {
+        (void)hipSetDevice(p->ctx->device);
+        ctx_release(p->ctx, p->d_counts); ctx_release(p->ctx, p->d_entries); ctx_release(p->ctx, p->pre_keys); ctx_release(p->ctx, p->pre_key_off);
+    }
     delete p;
 }
 
@@ -2056,7 +2268,7 @@ int ipkgpu_merge_parts(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t own
     if (!db) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
     db->ctx = ctx;
     struct Guard { ipkgpu_db* r; ~Guard() { if (r) ipkgpu_db_free(r); } } guard{db};
-    Stopwatch sw(ctx->stream);
+    Stopwatch sw(ctx->stream, &ctx->events);
     const int t0 = sw.mark();
     std::vector<const uint32_t*> crow(n_sources);
     std::vector<const uint2*> srow(n_sources);
@@ -2090,7 +2302,7 @@ int ipkgpu_merge_parts_ptrs(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_
     if (!db) return fail(ctx, IPKGPU_ERR_NOMEM, "out of host memory");
     db->ctx = ctx;
     struct Guard { ipkgpu_db* r; ~Guard() { if (r) ipkgpu_db_free(r); } } guard{db};
-    Stopwatch sw(ctx->stream);
+    Stopwatch sw(ctx->stream, &ctx->events);
     const int t0 = sw.mark();
     std::vector<const uint32_t*> crow(counts_dev, counts_dev + n_sources);
     std::vector<const uint2*> srow(n_sources);
@@ -2119,7 +2331,18 @@ int ipkgpu_db_from_parts(ipkgpu_ctx* ctx, ipkgpu_parts* parts, uint32_t sigma, u
     db->ctx = ctx;
     struct Guard { ipkgpu_db* r; ~Guard() { if (r) ipkgpu_db_free(r); } } guard{db};
     const uint64_t slots = parts->slots;
-    Stopwatch sw(ctx->stream);
+    if (parts->pre_keys) {                     // the scoring call built the key list already
+        db->d_keys = parts->pre_keys; db->d_key_off = parts->pre_key_off; db->n_keys = parts->pre_n_keys;
+        parts->pre_keys = nullptr; parts->pre_key_off = nullptr;
+        db->n_entries = parts->owner_off[1];
+        db->d_entries = parts->d_entries;      // ownership moves to the database
+        parts->d_entries = nullptr;
+        db->t_merge = parts->t_keys;
+        guard.r = nullptr;
+        *out = db;
+        return IPKGPU_OK;
+    }
+    Stopwatch sw(ctx->stream, &ctx->events);
     const int t0 = sw.mark();
     // single source, single owner: the entries are already in database order; only the key list
     // (non-empty slots) and its offsets have to be produced
@@ -2132,11 +2355,13 @@ int ipkgpu_db_from_parts(ipkgpu_ctx* ctx, ipkgpu_parts* parts, uint32_t sigma, u
     HIP_TRY(ctx, hipGetLastError());
     RC_TRY(scan_u32(ctx, parts->d_counts, slots, ctx->tmp_b.as<uint64_t>()));
     RC_TRY(scan_u32(ctx, ctx->tmp_a.as<uint32_t>(), slots, ctx->offsets.as<uint64_t>()));
-    uint64_t n_keys = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_keys, ctx->offsets.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_keys, std::max<uint64_t>(n_keys, 1) * 4));
-    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_key_off, (n_keys + 1) * 8));
+    // (no wait for the number of keys: it cannot exceed the slots nor the entries, the key arrays are allocated for that bound --
+    //  at most 12 bytes per slot next to 8 bytes per entry -- and the count itself comes back with the call's last wait)
+    const uint64_t keys_bound = std::max<uint64_t>(1, std::min<uint64_t>(slots, parts->owner_off[1]));
+    uint64_t* h_keys = reinterpret_cast<uint64_t*>(ctx->h_rb) + RB_OWNER_OFF;
+    HIP_TRY(ctx, hipMemcpyAsync(h_keys, ctx->offsets.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_keys, keys_bound * 4));
+    HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_key_off, (keys_bound + 1) * 8));
     const uint32_t nbk = (uint32_t)((slots + 1 + 255) / 256);
     if (sigma == 4)
         hipLaunchKernelGGL(merge_write_keys_kernel<4>, dim3(nbk), dim3(256), 0, ctx->stream, ctx->counts.as<uint32_t>(),
@@ -2147,7 +2372,7 @@ int ipkgpu_db_from_parts(ipkgpu_ctx* ctx, ipkgpu_parts* parts, uint32_t sigma, u
     HIP_TRY(ctx, hipGetLastError());
     const int t1 = sw.mark();
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    db->n_keys = n_keys;
+    db->n_keys = *h_keys;
     db->n_entries = parts->owner_off[1];
     db->d_entries = parts->d_entries;          // ownership moves to the database
     parts->d_entries = nullptr;
@@ -2196,7 +2421,7 @@ int ipkgpu_db_filter_mif0(ipkgpu_ctx* ctx, ipkgpu_db* db, uint64_t total_num_gro
     HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_fv32, std::max<uint64_t>(n, 1) * 4));
     HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_order, std::max<uint64_t>(n, 1) * 4));
     if (n == 0) return IPKGPU_OK;
-    Stopwatch sw(ctx->stream);
+    Stopwatch sw(ctx->stream, &ctx->events);
     const int t0 = sw.mark();
     hipLaunchKernelGGL(mif0_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, ctx->stream, db->d_key_off, db->d_entries, n,
                        (double)total_num_groups, (double)threshold, db->d_fv64, db->d_fv32);

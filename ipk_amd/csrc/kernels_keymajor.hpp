@@ -182,9 +182,12 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* __restr
 __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restrict__ table, uint64_t T, uint32_t G,
                                                        const uint32_t* __restrict__ branch_of_group, uint32_t P,
                                                        uint64_t slots, uint64_t* __restrict__ cursor,
-                                                       uint2* __restrict__ entries)
+                                                       uint2* __restrict__ entries, uint64_t cap_entries)
 {
     __shared__ uint32_t tile[64][65];
+    // (cap_entries: `entries` may have been allocated from an estimate, before the host knew the total -- cursor[P * slots], the
+    //  end of the scan; a writer that finds less room than that leaves everything untouched and the host runs it again)
+    if (cursor[(uint64_t)P * slots] > cap_entries) return;
     const uint64_t x0 = (uint64_t)blockIdx.x * 64;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     // this wavefront's 16 keys x0 + wave + 4 t: their output positions as scalar pointers, advanced by the popcount of each
@@ -244,10 +247,11 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
 __global__ __launch_bounds__(256) void km_write_c_generic_kernel(CompTable ct, uint64_t T, uint32_t G,
                                                          const uint32_t* __restrict__ branch_of_group, uint32_t P,
                                                          uint64_t slots, uint64_t* __restrict__ cursor,
-                                                         uint2* __restrict__ entries)
+                                                         uint2* __restrict__ entries, uint64_t cap_entries)
 {
     __shared__ uint32_t tile[64][65];
     __shared__ uint64_t run[64];
+    if (cursor[(uint64_t)P * slots] > cap_entries) return;       // (see km_write_kernel)
     __shared__ uint64_t row_mask[64];
     __shared__ const uint32_t* row_vals[64];
     const uint64_t nblocks = (T + 63) / 64, per_xcd = (nblocks + 7) / 8;
@@ -341,9 +345,10 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
                                                          const uint32_t* __restrict__ branch_of_group, uint32_t P,
                                                          uint64_t slots, const uint32_t* __restrict__ counts,
                                                          const uint32_t* __restrict__ qpack,
-                                                         uint64_t* __restrict__ cursor, uint2* __restrict__ entries)
+                                                         uint64_t* __restrict__ cursor, uint2* __restrict__ entries, uint64_t cap_entries)
 {
     __shared__ uint2 out[CAP];
+    if (cursor[(uint64_t)P * slots] > cap_entries) return;       // (see km_write_kernel)
     __shared__ uint4 rowmeta[4][64];                         // per wavefront and row: occupancy bits, address of the values
     __shared__ uint32_t rowbr[4][64];                        //                        branch id
     __shared__ uint32_t kpre[65];                            // exclusive prefix of the block's per-key entry counts

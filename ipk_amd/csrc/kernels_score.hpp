@@ -51,16 +51,29 @@ __global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict
             float acc = carry;
             float4* c4 = reinterpret_cast<float4*>(cm);
             const uint32_t n16 = n / 16;
-            float4 nx0, nx1, nx2, nx3;
-            if (n16) { nx0 = c4[0]; nx1 = c4[1]; nx2 = c4[2]; nx3 = c4[3]; }
-            for (uint32_t q = 0; q < n16; ++q) {
-                float4 v0 = nx0, v1 = nx1, v2 = nx2, v3 = nx3;
-                if (q + 1 < n16) { nx0 = c4[4 * q + 4]; nx1 = c4[4 * q + 5]; nx2 = c4[4 * q + 6]; nx3 = c4[4 * q + 7]; }
-                acc += v0.x; v0.x = acc; acc += v0.y; v0.y = acc; acc += v0.z; v0.z = acc; acc += v0.w; v0.w = acc;
-                acc += v1.x; v1.x = acc; acc += v1.y; v1.y = acc; acc += v1.z; v1.z = acc; acc += v1.w; v1.w = acc;
-                acc += v2.x; v2.x = acc; acc += v2.y; v2.y = acc; acc += v2.z; v2.z = acc; acc += v2.w; v2.w = acc;
-                acc += v3.x; v3.x = acc; acc += v3.y; v3.y = acc; acc += v3.z; v3.z = acc; acc += v3.w; v3.w = acc;
-                c4[4 * q] = v0; c4[4 * q + 1] = v1; c4[4 * q + 2] = v2; c4[4 * q + 3] = v3;
+            // sixteen sums in place; two register sets take turns (A is added while B's reads are in flight and the other way
+            // round), spelled out so that no set is ever copied into the other
+            auto add16 = [&](float4& v0, float4& v1, float4& v2, float4& v3) {
+                v0.x = acc + v0.x; v0.y = v0.x + v0.y; v0.z = v0.y + v0.z; v0.w = v0.z + v0.w;
+                v1.x = v0.w + v1.x; v1.y = v1.x + v1.y; v1.z = v1.y + v1.z; v1.w = v1.z + v1.w;
+                v2.x = v1.w + v2.x; v2.y = v2.x + v2.y; v2.z = v2.y + v2.z; v2.w = v2.z + v2.w;
+                v3.x = v2.w + v3.x; v3.y = v3.x + v3.y; v3.z = v3.y + v3.z; v3.w = v3.z + v3.w;
+                acc = v3.w;
+            };
+            float4 a0, a1, a2, a3, b0, b1, b2, b3;
+            if (n16) { a0 = c4[0]; a1 = c4[1]; a2 = c4[2]; a3 = c4[3]; }
+            uint32_t q = 0;
+            for (; q + 2 <= n16; q += 2) {
+                b0 = c4[4 * q + 4]; b1 = c4[4 * q + 5]; b2 = c4[4 * q + 6]; b3 = c4[4 * q + 7];
+                add16(a0, a1, a2, a3);
+                c4[4 * q] = a0; c4[4 * q + 1] = a1; c4[4 * q + 2] = a2; c4[4 * q + 3] = a3;
+                if (q + 2 < n16) { a0 = c4[4 * q + 8]; a1 = c4[4 * q + 9]; a2 = c4[4 * q + 10]; a3 = c4[4 * q + 11]; }
+                add16(b0, b1, b2, b3);
+                c4[4 * q + 4] = b0; c4[4 * q + 5] = b1; c4[4 * q + 6] = b2; c4[4 * q + 7] = b3;
+            }
+            if (q < n16) {
+                add16(a0, a1, a2, a3);
+                c4[4 * q] = a0; c4[4 * q + 1] = a1; c4[4 * q + 2] = a2; c4[4 * q + 3] = a3;
             }
             for (uint32_t j = n16 * 16; j < n; ++j) { acc += cm[j]; cm[j] = acc; }
             carry = acc;
@@ -714,12 +727,16 @@ __global__ __launch_bounds__(256) void ovf_group_keys_kernel(const unsigned long
 // (the reference's `count`, db_builder.cpp:664) to this pass instead of counting per step.  Grid-stride over the
 // descriptors with at most a few thousand workgroups: one atomic per workgroup on the total (a single word takes
 // ~88 returning atomics per microsecond chip-wide, so one per wavefront of descriptors would cost milliseconds).
+// (n_dev: the number of chunk ids drawn, still on the device -- a call that does not wait for it on the host passes the pool's
+//  capacity as n and the counter here; both kernels then stop at min(*n_dev, n))
 __global__ __launch_bounds__(256) void chunk_hist_kernel(const unsigned long long* __restrict__ desc, uint32_t n,
                                                          uint32_t* __restrict__ cnt, unsigned long long* __restrict__ pairs,
-                                                         uint32_t* __restrict__ gb_pairs /* optional: pairs per (group, bucket) */)
+                                                         uint32_t* __restrict__ gb_pairs /* optional: pairs per (group, bucket) */,
+                                                         const uint32_t* __restrict__ n_dev = nullptr)
 {
     __shared__ unsigned long long wsum[4];
     unsigned long long c = 0;
+    if (n_dev) n = min(n, *n_dev);
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const unsigned long long d = desc[i];
         if ((uint32_t)d != 0u) {
@@ -740,14 +757,22 @@ __global__ __launch_bounds__(256) void chunk_hist_kernel(const unsigned long lon
 }
 __global__ __launch_bounds__(256) void chunk_scatter_kernel(const unsigned long long* __restrict__ desc, uint32_t n,
                                                             const uint64_t* __restrict__ off, uint32_t* __restrict__ cur,
-                                                            uint2* __restrict__ list)
+                                                            uint2* __restrict__ list, const uint32_t* __restrict__ n_dev = nullptr)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long d = desc[i];
-    if ((uint32_t)d == 0u) return;
-    const uint32_t gb = (uint32_t)(d >> 32);
-    list[off[gb] + atomicAdd(&cur[gb], 1u)] = make_uint2(i, (uint32_t)d);      // (chunk id, pair count)
+    if (n_dev) n = min(n, *n_dev);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned long long d = desc[i];
+        if ((uint32_t)d == 0u) continue;
+        const uint32_t gb = (uint32_t)(d >> 32);
+        list[off[gb] + atomicAdd(&cur[gb], 1u)] = make_uint2(i, (uint32_t)d);      // (chunk id, pair count)
+    }
+}
+
+// The per-batch counters of ctx->small in one launch (they were five 4-us fills): scored k-mers @0, big-list queue length @16,
+// chunk ids drawn @32 (starting behind the chunks handed out by position), pool-exhausted flag @36, spare counter @48.
+__global__ void small_reset_kernel(uint32_t* __restrict__ small, uint32_t pre_chunks)
+{
+    if (threadIdx.x < 14) small[threadIdx.x] = threadIdx.x == 8 ? pre_chunks : 0u;
 }
 
 // Occupancy bits of a finished LDS table slice (slots key0 .. key0 + nslots of one group; key0 a multiple of 64):

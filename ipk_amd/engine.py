@@ -537,7 +537,9 @@ def _score_groups_keymajor(self, logp, mat_group, k, log_eps, n_owners=1, sigma=
         n_mats, sites, sigma = logp.shape
         ptr = logp.data_ptr() if n_mats else 0
         import torch
-        torch.cuda.current_stream().synchronize()
+        st = torch.cuda.current_stream()
+        if not st.query():                     # whatever produced logp on torch's stream must be done (the engine has its own stream)
+            st.synchronize()
     else:
         ptr = int(logp)
     out = C.c_void_p()

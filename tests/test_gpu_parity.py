@@ -487,3 +487,82 @@ def test_row_per_lane_join_with_dense_rows(engine, k, alpha):
     mats = synth_matrices(4, 70, 4, alpha, 700 + k)
     check_against_oracle(engine, mats, [3, 3, 8, 8], k, co.log_threshold(1.5, 4, k))
     check_against_oracle(engine, mats, [3, 3, 8, 8], k, co.log_threshold(1.5, 4, k), device=True)
+
+
+def _db_arrays(eng, mats, groups, k, eps, sigma):
+    parts = eng.score_groups_keymajor(mats, groups, k, eps, n_owners=1)
+    db = eng.db_from_parts(parts, sigma, k)
+    br, sc = db.entries()
+    out = (parts.emitted, db.keys().copy(), db.key_offsets().copy(), br.copy(), sc.view(np.uint32).copy())
+    db.free(); parts.free()
+    return out
+
+
+def _same_db(a, b):
+    return a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+
+@pytest.mark.parametrize("sigma,k,sites", [(4, 10, 400), (4, 12, 200), (20, 6, 40)], ids=["dna_k10", "dna_k12_compressed", "aa_k6"])
+def test_calls_without_waits_match_calls_with_them(sigma, k, sites):
+    """From its second call on, a context's key-major build waits on the stream ONCE: the wait after pass 1 is skipped (chunk
+    index and reduce take the chunk count from the device), the scored count and the pool's state come back with the writer's
+    totals, and the writer's output is allocated from the previous call's size before the total is known.  debug_flags bit 6
+    switches all of that off; both ways give the same database, and the oracle's."""
+    n_groups = 6
+    alpha = 0.05 if sigma == 4 else 0.03
+    mats = synth_matrices(2 * n_groups, sites, sigma, alpha, 4242)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 3, 2)
+    eps = co.log_threshold(1.5, sigma, k)
+    plain = ipk_amd.Engine(0)
+    plain.set_option("debug_flags", 64)
+    eng = ipk_amd.Engine(0)
+    try:
+        want = _db_arrays(plain, mats, groups, k, eps, sigma)
+        full, emitted = _oracle_db(mats, groups, k, eps)
+        assert want[0] == emitted and len(want[1]) == len(full)
+        for i in range(4):                                            # call 0 calibrates; 1.. run without the waits
+            got = _db_arrays(eng, mats, groups, k, eps, sigma)
+            assert _same_db(got, want), "call %d differs" % i
+    finally:
+        eng.close(); plain.close()
+
+
+def test_writer_output_estimate_that_is_too_small():
+    """The key-major writer's output is allocated from the previous call's entry count; a call that produces MORE finds the
+    writer returning untouched and runs it again with the true size.  Same database as a fresh context's."""
+    sigma, k, sites, n_groups = 4, 10, 300, 6
+    eps = co.log_threshold(1.5, sigma, k)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32), 2)
+    sharp = synth_matrices(2 * n_groups, sites, sigma, 0.02, 77)       # few pairs per window
+    flat = synth_matrices(2 * n_groups, sites, sigma, 0.3, 78)         # many more
+    eng, fresh = ipk_amd.Engine(0), ipk_amd.Engine(0)
+    try:
+        a = _db_arrays(eng, sharp, groups, k, eps, sigma)
+        b = _db_arrays(eng, flat, groups, k, eps, sigma)               # estimate from `sharp`: too small
+        assert len(b[3]) > 1.2 * len(a[3]), "the second workload must have more entries for this test to mean anything"
+        assert _same_db(b, _db_arrays(fresh, flat, groups, k, eps, sigma))
+        c = _db_arrays(eng, sharp, groups, k, eps, sigma)              # and back: an estimate that is too large
+        assert _same_db(c, a)
+    finally:
+        eng.close(); fresh.close()
+
+
+def test_pool_that_runs_out_in_a_call_without_waits():
+    """A call that skipped the wait after pass 1 learns that its pair pool ran out only at its last wait: the batch is scored
+    again with a larger pool (debug_pool_chunks forces the small first attempt)."""
+    sigma, k, sites, n_groups = 4, 10, 500, 8
+    eps = co.log_threshold(1.5, sigma, k)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32), 2)
+    mats = synth_matrices(2 * n_groups, sites, sigma, 0.05, 1234)
+    eng, fresh = ipk_amd.Engine(0), ipk_amd.Engine(0)
+    try:
+        want = _db_arrays(fresh, mats, groups, k, eps, sigma)
+        first = _db_arrays(eng, mats, groups, k, eps, sigma)           # calibrates; the next call skips the waits
+        assert _same_db(first, want)
+        eng.set_option("debug_pool_chunks", 40)
+        again = _db_arrays(eng, mats, groups, k, eps, sigma)
+        assert _same_db(again, want)
+        eng.set_option("debug_pool_chunks", 0)
+        assert _same_db(_db_arrays(eng, mats, groups, k, eps, sigma), want)
+    finally:
+        eng.close(); fresh.close()
