@@ -106,7 +106,7 @@ struct ipkgpu_ctx {
     int64_t opt_pool_limit = 0;       // test knob: bytes the pair pool may take (0 = what the device has free)
     int64_t opt_pool_chunks = 0;      // test knob: size of the FIRST pair-pool attempt (forces the grow-and-redo path)
     DevBuf table, best, ovfq, counts, offsets, goff, idx, branch, scan_sums, scan_boff, tmp_a, tmp_b, tmp_c;
-    DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm;   // stream variant: pair pool, chunk descriptors, chunk index
+    DevBuf pool, desc, gbcnt, gboff, gbcur, clist, gm, tile_next;   // stream variant: pair pool, chunk descriptors, chunk index, tile counters
     DevBuf ptrs;                 // per-source pointer arrays of a merge
     DevBuf mask;                 // occupancy bits of ctx->table ([groups in batch][mask_words]) when mask_valid
     bool mask_valid = false;
@@ -381,7 +381,7 @@ void ipkgpu_destroy(ipkgpu_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->table, &ctx->best, &ctx->ovfq, &ctx->counts, &ctx->offsets, &ctx->goff, &ctx->idx,
                       &ctx->branch, &ctx->scan_sums, &ctx->scan_boff, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c,
-                      &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->mask,
+                      &ctx->pool, &ctx->desc, &ctx->gbcnt, &ctx->gboff, &ctx->gbcur, &ctx->clist, &ctx->gm, &ctx->tile_next, &ctx->mask,
                       &ctx->rank, &ctx->vaddr, &ctx->ucnt, &ctx->qpack, &ctx->xstart, &ctx->pcounts, &ctx->ptrs,
                       &ctx->cvals, &ctx->coff, &ctx->croom};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -1371,7 +1371,15 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         const bool pre_ok = use_quad && n_waves * NBK + 1024 <= cap && !(ctx->opt_flags & 32);
         const uint32_t pre_chunks = pre_ok ? (uint32_t)(n_waves * NBK) : 0u;
         // (one launch for the batch's counters -- a retry must not double count -- and the chunk counter's start)
-        hipLaunchKernelGGL(small_reset_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<uint32_t*>(ctx->small), pre_chunks);
+        // (and the groups' tile counters of the quad kernel: its workgroups draw their tiles; debug_flags bit 7: fixed ranges)
+        uint32_t* d_tile_next = nullptr;
+        // (only where a workgroup has at least four tiles to its name: with fewer there is nothing to balance and the draws cost)
+        if (use_quad && !(ctx->opt_flags & 128) && ((uint64_t)nb * s_tiles_per_mat >= 4ull * gb * S || (ctx->opt_flags & 256))) {
+            RC_TRY(ensure(ctx, ctx->tile_next, (size_t)gb * 4));
+            d_tile_next = ctx->tile_next.as<uint32_t>();
+        }
+        hipLaunchKernelGGL(small_reset_kernel, dim3((std::max<uint32_t>(gb, 14) + 255) / 256), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<uint32_t*>(ctx->small), pre_chunks, d_tile_next, gb, S);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemsetAsync(ctx->desc.p, 0, cap * 8, ctx->stream));   // ids drawn but never opened stay empty
 
@@ -1385,6 +1393,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot;
         sp.flags = (uint32_t)(ctx->opt_flags);
         sp.pre_chunks = pre_chunks;
+        sp.tile_next = d_tile_next;
         std::unique_ptr<Stopwatch> sw_own(new Stopwatch(ctx->stream, &ctx->events));
         Stopwatch& sw = *sw_own;
         const int ev_a = sw.mark();
@@ -1478,7 +1487,9 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
             RC_TRY(ensure(ctx, ctx->ucnt, n_gb * 4));
         }
         if (n_used) {
-            hipLaunchKernelGGL(chunk_scatter_kernel, dim3(std::min<uint32_t>((n_used + 255) / 256, 1u << 16)), dim3(256), 0, ctx->stream,
+            // (grid-stride: without the host's count the grid covers the chunks the call expects, not the pool's capacity)
+            const uint64_t n_grid = spec ? std::min<uint64_t>(n_used, expected_chunks * 2 + n_waves * NBK + 4096) : n_used;
+            hipLaunchKernelGGL(chunk_scatter_kernel, dim3((uint32_t)std::min<uint64_t>((n_grid + 255) / 256, 1u << 16)), dim3(256), 0, ctx->stream,
                                ctx->desc.as<unsigned long long>(), n_used, ctx->gboff.as<uint64_t>(), d_gbcur,
                                ctx->clist.as<uint2>(), n_used_dev);
             HIP_TRY(ctx, hipGetLastError());

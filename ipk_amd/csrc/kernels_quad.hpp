@@ -453,13 +453,23 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
         }
     }
 
-    for (uint32_t t = t_lo; t < t_hi; ++t) {
+    // Tiles: a fixed range per workgroup, or -- p.tile_next -- drawn one at a time from the group's counter, so that the group's S
+    // workgroups finish together whatever their tiles held (a launch of ONE round of resident workgroups, a rank's share of a
+    // strong-scaled build, otherwise lasts as long as its slowest workgroup).  The next tile's number is drawn while this one is
+    // staged: thread 0 issues the atomic ahead of its staging loads and parks the result in LDS behind them.
+    __shared__ uint32_t sh_tile;
+    const bool draw = p.tile_next != nullptr;
+    uint32_t t = t_lo, t_end = t_hi;
+    if (draw) { t = seg; t_end = total_tiles; }            // (the first tile by position -- the counters start at S: no burst of atomics at launch)
+    while (t < t_end) {
         const uint32_t q = t / p.tiles_per_mat, tile = t - q * p.tiles_per_mat;
         const uint32_t mat = p.gm_list[m0 + q];
         const uint32_t t0 = tile * TW;
         const uint32_t nw = min((uint32_t)TW, p.nwin - t0);
         const uint32_t ncol = nw + K - 1;
-        __syncthreads();                                   // previous tile fully consumed
+        __syncthreads();                                   // previous tile fully consumed (and its sh_tile read by everyone)
+        uint32_t t_drawn = 0;
+        if (draw && threadIdx.x == 0) t_drawn = atomicAdd(&p.tile_next[g], 1u);
         {
             const float4* src = reinterpret_cast<const float4*>(p.logp + ((size_t)mat * p.sites + t0) * SIGMA);
             float4* dst = reinterpret_cast<float4*>(cols);
@@ -468,6 +478,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
             const float* bsrc = p.best + (size_t)mat * (p.sites + 1) + t0;
             for (uint32_t i = threadIdx.x; i <= ncol; i += NW * 64) best[i] = bsrc[i];
         }
+        if (draw && threadIdx.x == 0) sh_tile = t_drawn;
         __syncthreads();
         // the tile's thresholds: one thread per window
         for (uint32_t w = threadIdx.x; w < nw; w += NW * 64) {
@@ -745,6 +756,7 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                 }
             }
         }
+        t = draw ? sh_tile : t + 1;                        // (sh_tile: written before the barrier behind the staging, rewritten only after the next one)
     }
     if (!count_only) app.close();
     if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);       // (flags 2 / 4 only: otherwise the pairs are counted from the chunk descriptors)

@@ -339,9 +339,13 @@ struct StreamParams {
     uint32_t flags;                // diagnostics (timing experiments and tests; results are wrong with bits 0, 1, 2, 4 set):
                                    // bit 0 = skip the pool stores, bit 1 = skip the append bookkeeping too (row-per-lane join: no store pass),
                                    // bit 2 = list building only, bit 3 = quad kernel rebases its store window every 8 chunks (tests),
-                                   // bit 4 = row-per-lane join: count pass only; (host) bit 5 = no first chunks by position
+                                   // bit 4 = row-per-lane join: count pass only; (host) bit 5 = no first chunks by position,
+                                   // (host) bit 6 = every wait of the call as in round 2 (no device-side counts, no estimated allocations),
+                                   // (host) bit 7 = fixed tile ranges, bit 8 = drawn tiles whatever the tile count (tests)
     uint32_t pre_chunks;           // row-per-lane quad kernel: chunks [0, pre_chunks) are handed out by position -- wavefront w's bucket b
                                    // starts in chunk w * NB + b -- and pool_next starts at pre_chunks (0: every first chunk is drawn)
+    uint32_t* tile_next = nullptr; // quad kernel: [groups] next tile of each group -- its S workgroups DRAW their tiles instead of
+                                   // owning a fixed range each (nullptr: fixed ranges); set to S before the launch (tile `seg` is a workgroup's first)
 };
 
 // M with floor(t / n) == (t * M) >> 16 for 0 <= t < 128, 1 <= n <= 64   (M = ceil(65536 / n))
@@ -770,9 +774,12 @@ __global__ __launch_bounds__(256) void chunk_scatter_kernel(const unsigned long 
 
 // The per-batch counters of ctx->small in one launch (they were five 4-us fills): scored k-mers @0, big-list queue length @16,
 // chunk ids drawn @32 (starting behind the chunks handed out by position), pool-exhausted flag @36, spare counter @48.
-__global__ void small_reset_kernel(uint32_t* __restrict__ small, uint32_t pre_chunks)
+__global__ void small_reset_kernel(uint32_t* __restrict__ small, uint32_t pre_chunks, uint32_t* __restrict__ tile_next, uint32_t n_groups,
+                                   uint32_t first_tile)
 {
-    if (threadIdx.x < 14) small[threadIdx.x] = threadIdx.x == 8 ? pre_chunks : 0u;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 14) small[i] = i == 8 ? pre_chunks : 0u;
+    if (tile_next && i < n_groups) tile_next[i] = first_tile;   // (the quad kernel's per-group tile counters ride along: tiles [0, S) go by position)
 }
 
 // Occupancy bits of a finished LDS table slice (slots key0 .. key0 + nslots of one group; key0 a multiple of 64):

@@ -566,3 +566,22 @@ def test_pool_that_runs_out_in_a_call_without_waits():
         assert _same_db(_db_arrays(eng, mats, groups, k, eps, sigma), want)
     finally:
         eng.close(); fresh.close()
+
+
+@pytest.mark.parametrize("k", [8, 10, 11, 12])
+def test_workgroups_that_draw_their_tiles(k):
+    """The quad kernel's workgroups of a group draw their tiles from the group's counter (first tile by position) where a
+    workgroup has four or more to do; debug_flags bit 8 forces that on small inputs, bit 7 forces fixed ranges.  Same sets,
+    same scored counts as the oracle either way -- which workgroup scores a window does not matter."""
+    sigma, sites = 4, 900
+    mats = synth_matrices(6, sites, sigma, 0.08, 500 + k)
+    groups = np.array([4, 4, 9, 9, 9, 2], dtype=np.uint32)
+    eps = co.log_threshold(1.5, sigma, k)
+    for flags in (256, 128):
+        eng = ipk_amd.Engine(0)
+        try:
+            eng.set_option("debug_flags", flags)
+            check_against_oracle(eng, mats, groups, k, eps)
+            check_against_oracle(eng, mats, groups, k, eps)          # second call: pool calibrated, no wait after pass 1
+        finally:
+            eng.close()
