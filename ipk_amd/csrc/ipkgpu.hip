@@ -2081,8 +2081,10 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
 
         // One owner, the whole call in one batch, a key space of moderate size: the database's key list is built here, from the counts
         // and their scan BEFORE the writer advances it -- ipkgpu_db_from_parts would scan the counts again, in a call of its own
-        // with two more waits (a tenth of a 125-group share of cfg2).  The arrays are sized for every slot (12 bytes each).
-        const bool pre_keys = P == 1 && g0 == 0 && gb == n_groups && slots <= (1ull << 24) && rb_ok && !(ctx->opt_flags & 64);
+        // with two more waits (a tenth of a 125-group share of cfg2; 1.3 ms at cfg4).  The arrays are sized for every slot (12 bytes each).
+        // (larger key spaces -- AA k=6: 64 M slots -- only where the previous call's entries dwarf those 12 bytes per slot)
+        const bool pre_keys = P == 1 && g0 == 0 && gb == n_groups && rb_ok && !(ctx->opt_flags & 64) &&
+                              (slots <= (1ull << 24) || ctx->last_entries * 8 >= slots * 12 * 4);
         uint32_t* k_keys = nullptr; uint64_t* k_off = nullptr;
         struct KGuard { ipkgpu_ctx* c; uint32_t*& a; uint64_t*& b; ~KGuard() { ctx_release(c, a); ctx_release(c, b); } } kguard{ctx, k_keys, k_off};
         int kt0 = -1, kt1 = -1;
