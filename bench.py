@@ -250,6 +250,14 @@ def main():
     emitted = entries = n_keys = 0
     exchange_kind = "none"
 
+    # several ranks: the piece count of the exchange overlap is settled once (every step has the same shape), not by two
+    # all-reduces per step
+    n_pieces = None
+    if world > 1 and args.output != "group":
+        env = os.environ.get("IPK_DIST_PIECES")
+        want = int(env) if env else D.default_pieces(len(np.unique(groups)))
+        n_pieces = D.agree_on_pieces(groups, max(1, want), dist, "cpu" if dist.get_backend() == "gloo" else "cuda")
+
     def step(record):
         nonlocal emitted, entries, n_keys, exchange_kind
         if args.output == "group":
@@ -257,7 +265,8 @@ def main():
             emitted, entries = r.emitted, r.num_entries
             t = r
         else:
-            db, t = D.build_db_shard(eng, d_logp, groups, k, eps, sigma, dist if world > 1 else None, world, rank)
+            db, t = D.build_db_shard(eng, d_logp, groups, k, eps, sigma, dist if world > 1 else None, world, rank,
+                                     pieces=n_pieces, agreed=n_pieces is not None)
             emitted, entries, n_keys = t.emitted, db.num_entries, db.num_keys
             exchange_kind = getattr(t, "exchange", "none")
             if record:

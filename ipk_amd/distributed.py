@@ -128,14 +128,15 @@ def init_native_comm(engine, dist, world, rank):
     return True
 
 
-def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=1, rank=0, overlap=True, pieces=None):
+def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=1, rank=0, overlap=True, pieces=None, agreed=False):
     """Scores this rank's groups and returns (this rank's database shard, parts) -- the state
     `_phylo_kmer_db` has after explore_kmers (db_builder.cpp:576-627), sharded by k-mer owner.
 
     With several ranks the groups are scored in `pieces` contiguous ranges (default: default_pieces(), or IPK_DIST_PIECES) so that the
     exchange of one range's blocks runs while the next range is being scored -- only the last range's transfer is
     exposed; the merge takes pieces x world sources in the order (rank 0 piece 0, rank 0 piece 1, ..., rank 1 piece 0, ...),
-    which is global group order.  All ranks use the same piece count (agree_on_pieces)."""
+    which is global group order.  All ranks use the same piece count (agree_on_pieces: two small all-reduces per call, unless the
+    caller settled the count beforehand -- `pieces` from agree_on_pieces() with agreed=True, as a loop over equally shaped calls does)."""
     if world == 1:
         parts = engine.score_groups_keymajor(logp, mat_group, k, log_eps, n_owners=1)
         return engine.db_from_parts(parts, sigma, k), parts
@@ -148,7 +149,7 @@ def build_db_shard(engine, logp, mat_group, k, log_eps, sigma, dist=None, world=
     want = pieces if pieces is not None else (int(env) if env else default_pieces(len(np.unique(mat_group))))
     if not (overlap and hasattr(logp, "data_ptr")):
         want = 1
-    n = agree_on_pieces(mat_group, max(1, want), dist, "cuda" if on_gpu else "cpu")
+    n = max(1, want) if agreed else agree_on_pieces(mat_group, max(1, want), dist, "cuda" if on_gpu else "cpu")
     cuts = piece_cuts(mat_group, n) if n > 1 else [0, len(mat_group)]
     native = init_native_comm(engine, dist, world, rank)
 
