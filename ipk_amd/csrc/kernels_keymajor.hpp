@@ -321,7 +321,11 @@ __device__ __forceinline__ uint32_t lds_address(const void* p)
 // dec_score_bits without a select (the select form inside the copy loops below crashes this compiler's instruction selection)
 __device__ __forceinline__ uint32_t dec_score_bits_bf(uint32_t e) { return e ^ ~((uint32_t)((int32_t)e >> 31) >> 1); }
 
-constexpr uint32_t KMC_CAP = 5632;       // entries of a key block staged in LDS at once (44 KiB + 6 KiB of row data: three workgroups per CU)
+#ifndef IPK_KMC_CAP
+#define IPK_KMC_CAP 5632
+#endif
+constexpr uint32_t KMC_CAP = IPK_KMC_CAP;   // entries of a key block staged in LDS at once (44 KiB + 6 KiB of row data: three workgroups per CU;
+                                            // 3840 / 2816 for four / five measured equal at a cfg3 share and 13-17 % slower at cfg4: more rounds per block)
 
 // km_write_kernel reading the compressed form, for batches of up to 256 groups.  Workgroup w takes key block
 // (w % 8) * ceil(blocks / 8) + w / 8: workgroups are dealt round-robin to the 8 XCDs, so each XCD walks one contiguous range
@@ -340,6 +344,9 @@ constexpr uint32_t KMC_CAP = 5632;       // entries of a key block staged in LDS
 //            per-quarter counts the counting kernel leaves in qpack;
 //   copy     the staged block leaves as one linear, fully coalesced copy (scores decoded here, where all lanes are busy).
 // A block whose entries exceed the LDS stage is done in several key ranges (greedy split at key boundaries).
+// (Measured at cfg4, 19.3 ms: 14.2 without the value loads, 14.7 without the stores (IPK_KMC_NOLOAD / IPK_KMC_NOSTORE builds) -- neither
+//  memory side is the bound alone; rows broadcast from lane registers with v_readlane instead of the LDS round trip: 25.9 ms, and
+//  4.46 against 3.56 ms at a cfg3 share -- seven v_readlane per row cost more than the three broadcast reads they replace.)
 template <bool ONE_OWNER, uint32_t CAP>
 __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t T, uint32_t G,
                                                          const uint32_t* __restrict__ branch_of_group, uint32_t P,
@@ -410,7 +417,11 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
                 const uint4 mv = rowmeta[wave][b8 + u];                                  // (same address in every lane: a broadcast read)
                 const uint32_t j = __builtin_amdgcn_mbcnt_hi(mv.y, __builtin_amdgcn_mbcnt_lo(mv.x, 0u));
                 const uint32_t* vals = reinterpret_cast<const uint32_t*>(((uint64_t)mv.w << 32) | mv.z);
+#ifdef IPK_KMC_NOLOAD            // timing experiment: no value loads (results wrong)
+                val[b8 + u] = j + (uint32_t)(uintptr_t)vals;
+#else
                 val[b8 + u] = __builtin_nontemporal_load(vals + j);
+#endif
             }
         }
     }
@@ -466,7 +477,11 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
             for (uint32_t i = threadIdx.x; i < n_part; i += 256) {
                 uint2 e = out[i];
                 e.y = dec_score_bits_bf(e.y);
+#ifdef IPK_KMC_NOSTORE           // timing experiment: (almost) no stores (results wrong)
+                if (e.x == 0xFFFFFFF1u) dst[i] = e;
+#else
                 dst[i] = e;
+#endif
             }
         } else {
             for (uint32_t t = ka + wave; t < ke; t += 4) {
