@@ -346,7 +346,9 @@ constexpr uint32_t KMC_CAP = IPK_KMC_CAP;   // entries of a key block staged in 
 // A block whose entries exceed the LDS stage is done in several key ranges (greedy split at key boundaries).
 // (Measured at cfg4, 19.3 ms: 14.2 without the value loads, 14.7 without the stores (IPK_KMC_NOLOAD / IPK_KMC_NOSTORE builds) -- neither
 //  memory side is the bound alone; rows broadcast from lane registers with v_readlane instead of the LDS round trip: 25.9 ms, and
-//  4.46 against 3.56 ms at a cfg3 share -- seven v_readlane per row cost more than the three broadcast reads they replace.)
+//  4.46 against 3.56 ms at a cfg3 share -- seven v_readlane per row cost more than the three broadcast reads they replace; bits and
+//  branch id of a row in ONE 16-byte broadcast read for the scatter (three LDS instructions per row instead of four, stage 5248):
+//  3.54 ms at the cfg3 share, 20.4 at cfg4 -- the LDS pipe is not the bound either.)
 template <bool ONE_OWNER, uint32_t CAP>
 __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t T, uint32_t G,
                                                          const uint32_t* __restrict__ branch_of_group, uint32_t P,
