@@ -91,9 +91,16 @@ int64_t ipkgpu_debug_exec_violations(ipkgpu_ctx* ctx);
  * processed in batches that fit); "variant" (0 = auto: LDS max-reduce fed by the chunked pair pool, or by
  * the exact-partition passes for AA k=6; 1 = global-atomic max-reduce; 2 = force the chunked pool;
  * 3 = force the exact partition with dense tables; 4 = exact partition ending in compressed tables (occupancy
- * bits + rank + scores instead of dense per-group tables; what auto picks for AA k=6)); "debug_flags" /
- * "debug_pool_chunks" (diagnostics and tests only).
- * Every variant yields identical results.  Returns IPKGPU_ERR_INVALID for unknown names. */
+ * bits + rank + scores instead of dense per-group tables; what auto picks for AA k=6); 5 = ask for the quad kernel, 6 / 7 = force
+ * the compressed / the dense table form behind the chunked pool); "debug_flags" (bits 0-4: timing experiments inside the scoring
+ * kernels, results wrong; 5: no first chunks by position; 6: every host wait of a call kept -- no device-side counts, no
+ * allocations from estimates, no key list inside the scoring call; 7 / 8: the quad kernel's workgroups never / always draw
+ * their tiles), "debug_pool_chunks", "debug_pool_limit_bytes", "debug_wg_chunks2", "debug_rounds" (diagnostics and tests only).
+ * Every variant yields identical results.  Returns IPKGPU_ERR_INVALID for unknown names.
+ *
+ * Calls on one context are synchronous, but from its second scoring call on a context waits on its stream ONCE per key-major
+ * call: sizes it used to read back mid-call (chunks drawn, big-list windows, entry total) are taken from the previous call
+ * as estimates and checked at that one wait; a wrong estimate costs a repeated pass, never a wrong result. */
 int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value);
 
 /* ---- host helpers (no GPU needed) ------------------------------------------------------ */
