@@ -224,9 +224,14 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
 #pragma unroll
         for (uint32_t u = 0; u < 16; ++u) tile[wave + 4u * u][xl] = v[u];
         __syncthreads();
+        // (the sixteen columns are read before the first store: store8_lanes carries a "memory" clobber, so a read placed between
+        //  two stores is issued only after the earlier one -- sixteen exposed LDS round trips per tile instead of one)
+        uint32_t wq[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) wq[t] = tile[lane][wave + 4u * (uint32_t)t];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const uint32_t w = tile[lane][wave + 4u * (uint32_t)t];
+            const uint32_t w = wq[t];
             const uint64_t cm = ballot64(w != 0u);
             store8_lanes(dst[t], mbcnt(cm) << 3, br, dec_score_bits(w), cm);
             dst[t] += __popcll(cm);
@@ -322,10 +327,19 @@ __device__ __forceinline__ uint32_t lds_address(const void* p)
 __device__ __forceinline__ uint32_t dec_score_bits_bf(uint32_t e) { return e ^ ~((uint32_t)((int32_t)e >> 31) >> 1); }
 
 #ifndef IPK_KMC_CAP
-#define IPK_KMC_CAP 5632
+#define IPK_KMC_CAP 4224
 #endif
-constexpr uint32_t KMC_CAP = IPK_KMC_CAP;   // entries of a key block staged in LDS at once (44 KiB + 6 KiB of row data: three workgroups per CU;
-                                            // 3840 / 2816 for four / five measured equal at a cfg3 share and 13-17 % slower at cfg4: more rounds per block)
+#ifndef IPK_KMC_SB
+#define IPK_KMC_SB 8
+#endif
+#ifndef IPK_KMC_VB
+#define IPK_KMC_VB 8
+#endif
+typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;      // a pointer the compiler knows to be global memory
+constexpr uint32_t KMC_CAP = IPK_KMC_CAP;   // entries of a key block staged in LDS at once (33 KiB + 6 KiB of row data: four workgroups per CU.
+                                            // While the kernel needed 150+ VGPRs -- three wavefronts per SIMD -- a smaller stage bought nothing
+                                            // (3840 / 2816: equal at a cfg3 share, 13-17 % slower at cfg4); at 113 VGPRs 4224 is 2-3 % ahead of 5632
+                                            // at both, 3328 equal to 4224)
 
 // km_write_kernel reading the compressed form, for batches of up to 256 groups.  Workgroup w takes key block
 // (w % 8) * ceil(blocks / 8) + w / 8: workgroups are dealt round-robin to the 8 XCDs, so each XCD walks one contiguous range
@@ -416,11 +430,15 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
         if (b8 < nrows) {
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) {
+                if constexpr (IPK_KMC_VB < 8) { if ((u % IPK_KMC_VB) == 0) asm volatile("" ::: "memory"); }   // (bounds the rows whose reads are in flight: registers)
                 const uint4 mv = rowmeta[wave][b8 + u];                                  // (same address in every lane: a broadcast read)
                 const uint32_t j = __builtin_amdgcn_mbcnt_hi(mv.y, __builtin_amdgcn_mbcnt_lo(mv.x, 0u));
-                const uint32_t* vals = reinterpret_cast<const uint32_t*>(((uint64_t)mv.w << 32) | mv.z);
+                // (a GLOBAL load: through a generic pointer this was flat_load_dword, which counts on lgkmcnt as well -- the wait for
+                //  the next eight rows' broadcast reads then waited for these eight loads too, eight memory round trips per wavefront
+                //  one after the other)
+                const global_u32_ptr vals = (global_u32_ptr)(((uint64_t)mv.w << 32) | mv.z);
 #ifdef IPK_KMC_NOLOAD            // timing experiment: no value loads (results wrong)
-                val[b8 + u] = j + (uint32_t)(uintptr_t)vals;
+                val[b8 + u] = j + mv.z;
 #else
                 val[b8 + u] = __builtin_nontemporal_load(vals + j);
 #endif
@@ -443,19 +461,32 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
         // the rows' entries into the stage  (lanes outside the range never store; a whole block needs no masking)
         uint32_t posb = out_lds + (kpre[lane] - pre_a + before) * 8u;
         auto scatter = [&](auto WHOLE, uint32_t& pb) {                                  // (pb: an asm operand must not be a capture)
+            constexpr uint32_t SB = IPK_KMC_SB;                                          // rows whose bits and branch ids are read together
 #pragma unroll
             for (uint32_t b8 = 0; b8 < 64; b8 += 8) {
                 if (b8 < nrows) {
 #pragma unroll
-                    for (uint32_t u = 0; u < 8; ++u) {
-                        uint2 mm = *reinterpret_cast<const uint2*>(&rowmeta[wave][b8 + u]);
-                        if constexpr (!decltype(WHOLE)::value) { mm.x &= pm_lo; mm.y &= pm_hi; }
-                        u32x2_t e; e.x = rowbr[wave][b8 + u]; e.y = val[b8 + u];
-                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.x);
-                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.y);
-                        IPK_ASSERT_FULL_EXEC();
-                        asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, -1"
-                                     : "+v"(pb) : "v"(e), "s"(((uint64_t)hi << 32) | lo) : "memory");
+                    for (uint32_t b4 = 0; b4 < 8; b4 += SB) {
+                        // (the rows' bits and branch ids are read before the first of the asm statements: those carry a "memory"
+                        //  clobber, so a read placed between them is issued only after the previous row's write -- one exposed LDS round
+                        //  trip per row instead of one per SB rows)
+                        uint2 mmq[SB]; uint32_t brq[SB];
+                        asm volatile("" ::: "memory");                   // (fresh reads: reusing the value-load phase's copies would keep 128 registers alive)
+#pragma unroll
+                        for (uint32_t u = 0; u < SB; ++u) { mmq[u] = *reinterpret_cast<const uint2*>(&rowmeta[wave][b8 + b4 + u]); brq[u] = rowbr[wave][b8 + b4 + u]; }
+#pragma unroll
+                        for (uint32_t u = 0; u < SB; ++u) {
+                            uint2 mm = mmq[u];
+                            if constexpr (!decltype(WHOLE)::value) { mm.x &= pm_lo; mm.y &= pm_hi; }
+                            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.x);
+                            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.y);
+                            IPK_ASSERT_FULL_EXEC();
+                            // (branch and score as two 32-bit operands of one ds_write2_b32: as a 64-bit pair the compiler parks every
+                            //  val[] in the high half of a register pair -- 176 VGPRs, two wavefronts per SIMD)
+                            const uint32_t ex = brq[u], ey = val[b8 + b4 + u];          // (locals: an asm operand must not be a capture)
+                            asm volatile("s_mov_b64 exec, %3\n\tds_write2_b32 %0, %1, %2 offset1:1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, -1"
+                                         : "+v"(pb) : "v"(ex), "v"(ey), "s"(((uint64_t)hi << 32) | lo) : "memory");
+                        }
                     }
                 }
             }
