@@ -1573,6 +1573,22 @@ int scan_nonzero_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* 
     HIP_TRY(ctx, rocprim::exclusive_scan(ctx->scan_sums.p, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), ctx->stream));
     return IPKGPU_OK;
 }
+struct ScanRowsIn {
+    const uint32_t* const* rows; uint64_t slots, n;
+    __host__ __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)rows[i / slots][i % slots] : 0ull; }
+};
+// out[0 .. S * slots] = exclusive scan over S rows of `slots` counts laid end to end (rows: device array of device pointers)
+int scan_rows_u32(ipkgpu_ctx* ctx, const uint32_t* const* rows, uint32_t S, uint64_t slots, uint64_t* out)
+{
+    const uint64_t n = (uint64_t)S * slots;
+    if (n == 0) { HIP_TRY(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return IPKGPU_OK; }
+    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), ScanRowsIn{rows, slots, n});
+    size_t bytes = 0;
+    HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), ctx->stream));
+    RC_TRY(ensure(ctx, ctx->scan_sums, bytes));
+    HIP_TRY(ctx, rocprim::exclusive_scan(ctx->scan_sums.p, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), ctx->stream));
+    return IPKGPU_OK;
+}
 int scan_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out)
 {
     if (n == 0) { HIP_TRY(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return IPKGPU_OK; }
@@ -1919,15 +1935,18 @@ int merge_sources(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, u
                   const std::vector<const uint32_t*>& counts_rows, const std::vector<const uint2*>& src_rows,
                   uint32_t* total_out /*[slots] device*/, uint2** dst_out, uint64_t* n_total_out, ipkgpu_db* db)
 {
-    // workspaces: tmp_a = flags u32[slots] ; tmp_b = dst_off u64[slots+1] ; tmp_c = src_off u64[S][slots+1] ; goff = the pointer arrays
+    // workspaces: tmp_a = flags u32[slots] ; tmp_b = dst_off u64[slots+1] ; tmp_c = ONE scan over the sources' counts rows laid end to
+    // end, u64[S * slots + 1] (it was a scan per source: 2 S launches) ; ptrs = the pointer arrays (uploaded from pinned staging: no wait)
     RC_TRY(ensure(ctx, ctx->tmp_a, slots * 4));
     RC_TRY(ensure(ctx, ctx->tmp_b, (slots + 1) * 8));
-    RC_TRY(ensure(ctx, ctx->tmp_c, (size_t)S * (slots + 1) * 8));
+    RC_TRY(ensure(ctx, ctx->tmp_c, ((size_t)S * slots + 1) * 8));
     RC_TRY(ensure(ctx, ctx->ptrs, (size_t)S * 16));
-    std::vector<const void*> hp((size_t)2 * S);
+    void* stage = nullptr;
+    RC_TRY(upload_stage(ctx, (size_t)S * 16, &stage));
+    const void** hp = reinterpret_cast<const void**>(stage);
     for (uint32_t s = 0; s < S; ++s) { hp[s] = counts_rows[s]; hp[S + s] = src_rows[s]; }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ptrs.p, hp.data(), hp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                 // hp is a stack-lifetime pageable buffer
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ptrs.p, hp, (size_t)S * 16, hipMemcpyHostToDevice, ctx->stream));
+    RC_TRY(upload_staged(ctx));
     const uint32_t* const* d_counts = ctx->ptrs.as<const uint32_t*>();
     const uint2* const* d_src = reinterpret_cast<const uint2* const*>(ctx->ptrs.as<const void*>() + S);
     const uint32_t nb256 = (uint32_t)((slots + 255) / 256);
@@ -1935,11 +1954,11 @@ int merge_sources(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, u
                        ctx->tmp_a.as<uint32_t>());
     HIP_TRY(ctx, hipGetLastError());
     RC_TRY(scan_u32(ctx, total_out, slots, ctx->tmp_b.as<uint64_t>()));
-    for (uint32_t s = 0; s < S; ++s)
-        RC_TRY(scan_u32(ctx, counts_rows[s], slots, ctx->tmp_c.as<uint64_t>() + (size_t)s * (slots + 1)));
-    uint64_t n_total = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_total, ctx->tmp_b.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RC_TRY(scan_rows_u32(ctx, d_counts, S, slots, ctx->tmp_c.as<uint64_t>()));
+    uint64_t* h_tot = reinterpret_cast<uint64_t*>(ctx->h_rb) + RB_OWNER_OFF;        // (pinned: [0] entries, [1] keys)
+    HIP_TRY(ctx, hipMemcpyAsync(h_tot, ctx->tmp_b.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n_total = h_tot[0];
     uint2* dst = nullptr;
     HIP_TRY(ctx, ctx_alloc(ctx, (void**)&dst, std::max<uint64_t>(n_total, 1) * 8));
     if (slots) {
@@ -1950,14 +1969,14 @@ int merge_sources(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, u
     *n_total_out = n_total;
     HIP_TRY(ctx, hipGetLastError());
     if (db) {
-        // compact key list: scan of flags (reuses tmp_c as flag offsets: the copy kernel is stream-ordered before)
+        // compact key list: scan of flags; the key arrays are sized for min(slots, entries) keys, the count comes back with the
+        // caller's next wait on the stream (db->n_keys is read by the callers only after theirs)
         RC_TRY(ensure(ctx, ctx->offsets, (slots + 1) * 8));
         RC_TRY(scan_u32(ctx, ctx->tmp_a.as<uint32_t>(), slots, ctx->offsets.as<uint64_t>()));
-        uint64_t n_keys = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&n_keys, ctx->offsets.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_keys, std::max<uint64_t>(n_keys, 1) * 4));
-        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_key_off, (n_keys + 1) * 8));
+        HIP_TRY(ctx, hipMemcpyAsync(h_tot + 1, ctx->offsets.as<uint64_t>() + slots, 8, hipMemcpyDeviceToHost, ctx->stream));
+        const uint64_t keys_bound = std::max<uint64_t>(1, std::min<uint64_t>(slots, n_total));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_keys, keys_bound * 4));
+        HIP_TRY(ctx, ctx_alloc(ctx, (void**)&db->d_key_off, (keys_bound + 1) * 8));
         const uint32_t nbk = (uint32_t)((slots + 1 + 255) / 256);
         if (sigma == 4)
             hipLaunchKernelGGL(merge_write_keys_kernel<4>, dim3(nbk), dim3(256), 0, ctx->stream, total_out, ctx->offsets.as<uint64_t>(),
@@ -1966,6 +1985,8 @@ int merge_sources(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, u
             hipLaunchKernelGGL(merge_write_keys_kernel<20>, dim3(nbk), dim3(256), 0, ctx->stream, total_out, ctx->offsets.as<uint64_t>(),
                                ctx->tmp_b.as<uint64_t>(), slots, owner, P, (int)k, db->d_keys, db->d_key_off);
         HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                 // (the key count; also the end of the merge for the callers' timing)
+        const uint64_t n_keys = h_tot[1];
         db->n_keys = n_keys;
     }
     return IPKGPU_OK;

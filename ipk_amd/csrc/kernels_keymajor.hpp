@@ -18,6 +18,9 @@
 
 namespace ipkgpu {
 
+typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;      // a pointer the compiler knows to be global memory (no flat_load)
+
+
 // counts_perm[(x % P) * slots + x / P] = #groups g in [0, G) with table[g][x] != 0
 __global__ __launch_bounds__(256) void km_count_kernel(const uint32_t* __restrict__ table, uint64_t T, uint32_t G,
                                                        uint32_t P, uint64_t slots, uint32_t* __restrict__ counts)
@@ -335,7 +338,6 @@ __device__ __forceinline__ uint32_t dec_score_bits_bf(uint32_t e) { return e ^ ~
 #ifndef IPK_KMC_VB
 #define IPK_KMC_VB 8
 #endif
-typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;      // a pointer the compiler knows to be global memory
 constexpr uint32_t KMC_CAP = IPK_KMC_CAP;   // entries of a key block staged in LDS at once (33 KiB + 6 KiB of row data: four workgroups per CU.
                                             // While the kernel needed 150+ VGPRs -- three wavefronts per SIMD -- a smaller stage bought nothing
                                             // (3840 / 2816: equal at a cfg3 share, 13-17 % slower at cfg4); at 113 VGPRs 4224 is 2-3 % ahead of 5632
@@ -544,15 +546,18 @@ __global__ __launch_bounds__(256) void merge_sum_counts_kernel(const uint32_t* c
     const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= slots) return;
     uint32_t c = 0;
-    for (uint32_t s = 0; s < S; ++s) c += counts[s][q];
+    for (uint32_t s = 0; s < S; ++s) c += ((global_u32_ptr)counts[s])[q];
     total[q] = c;
     flags[q] = (c != 0u);
 }
 
 // One wavefront per slot: copies the slot's entries of every source, in source order.
-// src_off[s][q] = exclusive scan of source s's counts (relative to the source's own block).
+// goff = ONE exclusive scan over the sources' counts rows laid end to end ([S * slots + 1]): source s's entries of slot q start at
+// goff[s * slots + q] - goff[s * slots] inside the source's own block.  Lane s fetches source s's count, offset and base in one
+// round trip (sixty-four sources at a time); the copies then run source by source with everything they need in registers --
+// the first version walked the sources with three dependent loads each (pointer, count, offset) before the copy could start.
 __global__ __launch_bounds__(256) void merge_copy_kernel(const uint32_t* const* __restrict__ counts, uint32_t S, uint64_t slots,
-                                                         const uint64_t* __restrict__ src_off,   // [S][slots+1]
+                                                         const uint64_t* __restrict__ goff,      // [S * slots + 1]
                                                          const uint2* const* __restrict__ src,
                                                          const uint64_t* __restrict__ dst_off,   // [slots+1]
                                                          uint2* __restrict__ dst)
@@ -561,11 +566,38 @@ __global__ __launch_bounds__(256) void merge_copy_kernel(const uint32_t* const* 
     if (q >= slots) return;
     const uint32_t lane = lane_id();
     uint64_t d = dst_off[q];
-    for (uint32_t s = 0; s < S; ++s) {
-        const uint32_t n = counts[s][q];
-        const uint2* from = src[s] + src_off[(size_t)s * (slots + 1) + q];
-        for (uint32_t i = lane; i < n; i += 64) dst[d + i] = from[i];
-        d += n;
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        uint32_t n_s = 0;
+        uint64_t from_s = 0;
+        if (s < S) {
+            const global_u32_ptr row = (global_u32_ptr)counts[s];
+            n_s = row[q];
+            from_s = reinterpret_cast<uint64_t>(src[s]) + 8ull * (goff[(uint64_t)s * slots + q] - goff[(uint64_t)s * slots]);
+        }
+        const uint32_t ns = min(64u, S - s0);
+        // four sources per trip: their loads are issued together, then their stores
+        for (uint32_t t0 = 0; t0 < ns; t0 += 4) {
+            typedef const unsigned long long __attribute__((address_space(1)))* global_u64_ptr;   // (an entry as one 64-bit word)
+            unsigned long long* const dst64 = reinterpret_cast<unsigned long long*>(dst);
+            uint32_t n[4]; global_u64_ptr from[4]; unsigned long long v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t t = min(t0 + u, ns - 1);
+                n[u] = t0 + u < ns ? (uint32_t)__builtin_amdgcn_readlane((int)n_s, (int)t) : 0u;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)from_s, (int)t);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(from_s >> 32), (int)t);
+                from[u] = (global_u64_ptr)(((uint64_t)hi << 32) | lo);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) if (lane < n[u]) v[u] = from[u][lane];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                if (lane < n[u]) dst64[d + lane] = v[u];
+                for (uint32_t i = lane + 64; i < n[u]; i += 64) dst64[d + i] = from[u][i];   // (more than 64 entries of one source: rare)
+                d += n[u];
+            }
+        }
     }
 }
 

@@ -6,6 +6,7 @@ that ``explore_group`` leaves in ``group_map`` (db_builder.cpp:685), plus the nu
 phylo-k-mers (the reference's ``count``, db_builder.cpp:664).
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -251,7 +252,7 @@ class Engine:
                                                       gp, k, C.c_float(log_eps), C.byref(out))
         if rc != 0:
             raise self._err(rc)
-        return Result(self._lib, out)
+        return self._adopt(Result(self._lib, out))
 
     def score_groups_positions(self, logp, mat_group, k, log_eps):
         """KEEP_POSITIONS flavour (ipk-aa-pos): logp numpy float32 [n_mats, sites, sigma]; Result.positions()."""
@@ -266,10 +267,22 @@ class Engine:
                                                      C.byref(out))
         if rc != 0:
             raise self._err(rc)
-        return Result(self._lib, out)
+        return self._adopt(Result(self._lib, out))
+
+    def _adopt(self, obj):
+        """Results, parts and databases hold device blocks of this context: close() frees the ones still alive first (a handle freed
+        after its context is a crash, and a failing test leaves exactly that order to the garbage collector)."""
+        kids = self.__dict__.setdefault("_children", weakref.WeakSet())
+        kids.add(obj)
+        return obj
 
     def close(self):
         if self._h:
+            for kid in list(self.__dict__.get("_children", ())):
+                try:
+                    kid.free()
+                except Exception:
+                    pass
             self._lib.ipkgpu_destroy(self._h)
             self._h = None
 
@@ -549,7 +562,7 @@ def _score_groups_keymajor(self, logp, mat_group, k, log_eps, n_owners=1, sigma=
     del keep
     if rc != 0:
         raise self._err(rc)
-    return Parts(self._lib, out)
+    return self._adopt(Parts(self._lib, out))
 
 
 def _merge_parts(self, sigma, k, owner, n_owners, counts, entries, source_offsets):
@@ -564,7 +577,7 @@ def _merge_parts(self, sigma, k, owner, n_owners, counts, entries, source_offset
                                       so.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(out))
     if rc != 0:
         raise self._err(rc)
-    return Db(self._lib, out)
+    return self._adopt(Db(self._lib, out))
 
 
 def _merge_parts_ptrs(self, sigma, k, owner, n_owners, counts_ptrs, entries_ptrs):
@@ -577,7 +590,7 @@ def _merge_parts_ptrs(self, sigma, k, owner, n_owners, counts_ptrs, entries_ptrs
     rc = self._lib.ipkgpu_merge_parts_ptrs(self._h, sigma, k, owner, n_owners, n, cp, ep, C.byref(out))
     if rc != 0:
         raise self._err(rc)
-    return Db(self._lib, out)
+    return self._adopt(Db(self._lib, out))
 
 
 def _comm_unique_id(self):
@@ -633,7 +646,7 @@ def _exchange_merge(self, xfers, sigma, k):
         self._lib.ipkgpu_xfer_free(x)
     if rc != 0:
         raise self._err(rc)
-    return Db(self._lib, out), float(exposed.value)
+    return self._adopt(Db(self._lib, out)), float(exposed.value)
 
 
 def _db_from_parts(self, parts, sigma, k):
@@ -644,7 +657,7 @@ def _db_from_parts(self, parts, sigma, k):
     if rc != 0:
         raise self._err(rc)
     parts.owner_offsets = parts.owner_offsets.copy()
-    return Db(self._lib, out)
+    return self._adopt(Db(self._lib, out))
 
 
 Engine.db_from_parts = _db_from_parts

@@ -373,3 +373,34 @@ def test_compressed_writer_splits_dense_blocks(engine, n_groups, n_owners):
         check_shard(db, full, sigma, k, o, n_owners)
         db.free()
     parts.free()
+
+
+def test_merge_of_many_sources(engine):
+    """The owner-side merge with more sources than a wavefront has lanes (70: two rounds of 64, trips of four) and a source
+    that brings more than 64 entries for one k-mer (a 'rank' with 150 groups): merge_copy_kernel's every path, against the
+    oracle's database."""
+    import torch
+    sigma, k, sites, world = 4, 5, 30, 2
+    sizes_g = [150] + [1] * 69                                       # groups per emulated rank
+    n_groups = sum(sizes_g)
+    mats = synth_matrices(n_groups, sites, sigma, 1.0, 4711)            # flat columns: most k-mers pass in most groups
+    groups = np.arange(n_groups, dtype=np.uint32) + 11
+    eps = co.log_threshold(1.5, sigma, k)
+    full, emitted = oracle_db(mats, groups, k, eps)
+    parts, g0 = [], 0
+    for n in sizes_g:
+        parts.append(engine.score_groups_keymajor(mats[g0:g0 + n], groups[g0:g0 + n], k, eps, n_owners=world))
+        g0 += n
+    assert sum(p.emitted for p in parts) == emitted
+    for o in range(world):
+        counts = torch.stack([p.counts_tensor()[o] for p in parts]).contiguous()
+        assert int(counts[0].max()) > 64, "the first source must bring more than 64 entries for some k-mer"
+        blocks = [p.entries_tensor()[int(p.owner_offsets[o]):int(p.owner_offsets[o + 1])] for p in parts]
+        entries = torch.cat(blocks).contiguous()
+        so = np.concatenate([[0], np.cumsum([b.shape[0] for b in blocks])[:-1]]).astype(np.uint64)
+        torch.cuda.synchronize()
+        db = engine.merge_parts(sigma, k, o, world, counts, entries, so)
+        check_shard(db, full, sigma, k, o, world)
+        db.free()
+    for p in parts:
+        p.free()
