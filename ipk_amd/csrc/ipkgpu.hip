@@ -1554,13 +1554,20 @@ int score_batch(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint32_t
 // out[0..n] = exclusive scan of in[0..n)   (u32 -> u64; out[n] = the total): one single-pass device scan (rocPRIM, decoupled
 // look-back) over n + 1 items, the last one a zero -- two launches where the three-kernel scan (block sums, one workgroup over
 // the sums, apply) cost 27 us per call at a million keys, four times per scoring call.
+// (the scans' inputs are read through global pointers: as members of a functor they are generic ones to the compiler, and their
+//  loads FLAT -- tools/isa_flat.py)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IPK_GLOBAL_U32(p) ((ipkgpu::global_u32_ptr)(p))
+#else
+#define IPK_GLOBAL_U32(p) (p)
+#endif
 struct ScanU32In {
     const uint32_t* in; uint64_t n;
-    __host__ __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)in[i] : 0ull; }
+    __host__ __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)IPK_GLOBAL_U32(in)[i] : 0ull; }
 };
 struct ScanNonzeroIn {
     const uint32_t* in; uint64_t n;
-    __host__ __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)(in[i] != 0u) : 0ull; }
+    __host__ __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)(IPK_GLOBAL_U32(in)[i] != 0u) : 0ull; }
 };
 // out[0..n] = exclusive scan of (in[i] != 0): the position of every non-empty slot in the key list, out[n] = the number of keys
 int scan_nonzero_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* out)
@@ -1575,7 +1582,15 @@ int scan_nonzero_u32(ipkgpu_ctx* ctx, const uint32_t* in, uint64_t n, uint64_t* 
 }
 struct ScanRowsIn {
     const uint32_t* const* rows; uint64_t slots, n;
-    __host__ __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)rows[i / slots][i % slots] : 0ull; }
+    __host__ __device__ uint64_t operator()(uint64_t i) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const uint32_t* const __attribute__((address_space(1)))* rows_ptr;
+        return i < n ? (uint64_t)IPK_GLOBAL_U32(((rows_ptr)rows)[i / slots])[i % slots] : 0ull;
+#else
+        return i < n ? (uint64_t)rows[i / slots][i % slots] : 0ull;
+#endif
+    }
 };
 // out[0 .. S * slots] = exclusive scan over S rows of `slots` counts laid end to end (rows: device array of device pointers)
 int scan_rows_u32(ipkgpu_ctx* ctx, const uint32_t* const* rows, uint32_t S, uint64_t slots, uint64_t* out)

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void km_write_c_generic_kernel(CompTable ct, u
             const uint32_t gl = i >> 6, xl = i & 63u;
             const uint64_t m = row_mask[gl];
             uint32_t v = 0;
-            if ((m >> xl) & 1ull) v = row_vals[gl][(uint32_t)__popcll(m & ((1ull << xl) - 1ull))];
+            if ((m >> xl) & 1ull) v = ((global_u32_ptr)row_vals[gl])[(uint32_t)__popcll(m & ((1ull << xl) - 1ull))];
             tile[gl][xl] = v;
         }
         __syncthreads();

@@ -380,7 +380,7 @@ def test_merge_of_many_sources(engine):
     that brings more than 64 entries for one k-mer (a 'rank' with 150 groups): merge_copy_kernel's every path, against the
     oracle's database."""
     import torch
-    sigma, k, sites, world = 4, 5, 30, 2
+    sigma, k, sites, world = 4, 5, 200, 2
     sizes_g = [150] + [1] * 69                                       # groups per emulated rank
     n_groups = sum(sizes_g)
     mats = synth_matrices(n_groups, sites, sigma, 1.0, 4711)            # flat columns: most k-mers pass in most groups
