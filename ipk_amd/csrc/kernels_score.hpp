@@ -1166,8 +1166,18 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
                         }
                     }
                 } else {
+                    // (sixteen columns' broadcast reads in flight per LDS round trip: with four, a 135-entry list cost 34 exposed
+                    //  round trips per row block)
+                    uint32_t j = 0;
+                    for (; j + 16 <= nR; j += 16) {
+                        float by[16];
+#pragma unroll
+                        for (uint32_t u = 0; u < 16; ++u) by[u] = __uint_as_float(R[j + u].y);
+#pragma unroll
+                        for (uint32_t u = 0; u < 16; ++u) cnt += (ay + by[u] > p.eps) ? 1u : 0u;      // pk_compute.cpp:90-91
+                    }
 #pragma unroll 4
-                    for (uint32_t j = 0; j < nR; ++j) {
+                    for (; j < nR; ++j) {
                         const float s = ay + __uint_as_float(R[j].y);              // pk_compute.cpp:90
                         cnt += (s > p.eps) ? 1u : 0u;                              // :91
                     }
