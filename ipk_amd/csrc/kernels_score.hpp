@@ -968,6 +968,9 @@ __device__ __forceinline__ void xp_rank_by_counting(uint32_t n, const unsigned l
 // between a lane's own registers.  Keys are distinct (the position is part of them), padding keys are 0 and end up last.
 // n = 135 (the mean at AA k=6, four registers): 33 lane stages of 4 x ~7 instructions + 3 register stages against 135 x (2 readlanes
 // + 3 64-bit compares) for ranking by counting -- and no O(n^2).
+#ifndef IPK_SORT_DPP
+#define IPK_SORT_DPP 1
+#endif
 template <int NCH, int RC>
 __device__ __forceinline__ void xp_sort_desc(unsigned long long (&kj)[RC])
 {
@@ -996,8 +999,24 @@ __device__ __forceinline__ void xp_sort_desc(unsigned long long (&kj)[RC])
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const unsigned long long a = kj[c];
-                    const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)a);
-                    const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(a >> 32));
+                    uint32_t olo, ohi;
+                    if constexpr (IPK_SORT_DPP != 0) {
+                        // partners one or two lanes away sit in the same quad: a DPP move (no LDS round trip) -- 15 of the 33 lane stages
+                        // of a 256-key sort
+                        if (stride == 1) {
+                            olo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)a, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+                            ohi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(a >> 32), 0xB1, 0xF, 0xF, true);
+                        } else if (stride == 2) {
+                            olo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)a, 0x4E, 0xF, 0xF, true);          // quad_perm [2,3,0,1]
+                            ohi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(a >> 32), 0x4E, 0xF, 0xF, true);
+                        } else {
+                            olo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)a);
+                            ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(a >> 32));
+                        }
+                    } else {
+                        olo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)a);
+                        ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(a >> 32));
+                    }
                     const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
                     const uint32_t e = (uint32_t)c * 64u + lane;
                     const bool desc = (e & (uint32_t)size) == 0 || size == NCH * 64;
