@@ -220,7 +220,11 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
         for (uint32_t u = 0; u < 16; ++u) {
             const uint32_t gl = wave + 4u * u;
             v[u] = 0;
+#ifdef IPK_KMW_NOLOAD             // timing experiment: no table loads (results wrong)
+            if (g0 + gl < G && xok) v[u] = (uint32_t)(g0 + gl + x0 + xl) | 0x80000000u;
+#else
             if (g0 + gl < G && xok) v[u] = table[(size_t)(g0 + gl) * T + x0 + xl];
+#endif
         }
         const uint32_t br = (g0 + lane < G) ? branch_of_group[g0 + lane] : 0u;
         __syncthreads();                                     // the previous tile is consumed
@@ -236,7 +240,11 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
         for (int t = 0; t < 16; ++t) {
             const uint32_t w = wq[t];
             const uint64_t cm = ballot64(w != 0u);
+#ifdef IPK_KMW_NOSTORE            // timing experiment: (almost) no stores (results wrong)
+            store8_lanes(dst[t], mbcnt(cm) << 3, br, dec_score_bits(w), cm & (ballot64(w == 0x12345u) != 0 ? ~0ull : 0ull));
+#else
             store8_lanes(dst[t], mbcnt(cm) << 3, br, dec_score_bits(w), cm);
+#endif
             dst[t] += __popcll(cm);
         }
     }
