@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
         for (int t = 0; t < 16; ++t) {
             const uint32_t w = wq[t];
             const uint64_t cm = ballot64(w != 0u);
-#ifdef IPK_KMW_NOSTORE            // timing experiment: (almost) no stores (results wrong)
+#if defined(IPK_KMW_ALIGNED)      // timing experiment: every store a full, 512-byte aligned one (results wrong)
+            store8_lanes(reinterpret_cast<const void*>(reinterpret_cast<uintptr_t>(dst[t]) & ~(uintptr_t)511), lane_id() << 3, br, dec_score_bits(w), ~0ull);
+#elif defined(IPK_KMW_NOSTORE)    // timing experiment: (almost) no stores (results wrong)
             store8_lanes(dst[t], mbcnt(cm) << 3, br, dec_score_bits(w), cm & (ballot64(w == 0x12345u) != 0 ? ~0ull : 0ull));
 #else
             store8_lanes(dst[t], mbcnt(cm) << 3, br, dec_score_bits(w), cm);
