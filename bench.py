@@ -366,7 +366,8 @@ def main():
         else:
             kline(main_kernel, avg_main_ms, b_alg)
             kline("reduce_buckets_kernel", per_launch("reduce"), p_bytes + 4.0 * (sigma ** k) * ng)   # pairs in, dense tables out
-            kline("km_write_kernel", per_launch("km_write"), 4.0 * (sigma ** k) * ng + e_bytes)       # dense tables in, entries out
+            dense_writer = "km_write_kernel" if int(os.environ.get("IPKGPU_DEBUG_FLAGS", "0")) & 512 else "km_write_lines_kernel"
+            kline(dense_writer, per_launch("km_write"), 4.0 * (sigma ** k) * ng + e_bytes)             # dense tables in, entries out
         out = {
             "metric": "scored phylo-k-mers/sec", "value": value, "unit": "phylo-k-mers/s",
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "exchange": exchange_kind, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -2175,8 +2175,12 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
                     hipLaunchKernelGGL(km_write_c_generic_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
                                        comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
                                        ctx->offsets.as<uint64_t>(), b.entries, cap_e);
-            } else
+            } else if (ctx->opt_flags & 512)                 // (debug_flags bit 9: the writer whose stores follow the tiles, not the lines)
                 hipLaunchKernelGGL(km_write_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
+                                   ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
+                                   ctx->offsets.as<uint64_t>(), b.entries, cap_e);
+            else
+                hipLaunchKernelGGL(km_write_lines_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
                                    ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
                                    ctx->offsets.as<uint64_t>(), b.entries, cap_e);
             HIP_TRY(ctx, hipGetLastError());

@@ -258,6 +258,101 @@ __global__ __launch_bounds__(256) void km_write_kernel(const uint32_t* __restric
     if (mine) cursor[cidx] = fin;
 }
 
+// km_write_kernel with every store cut at a 128-byte line of the output.  The dense writer is bound by its stores, and those cost by
+// (cache line, instruction) requests and by partly written lines, not by bytes: a key's ~58 entries per 64-group tile are 464 bytes
+// at 8-byte alignment -- five lines touched, two of them partly -- and the same stores made full and aligned ran 27 % faster
+// (DESIGN.md, section 9).  Here a key's entries that do not fill a line stay behind as a TAIL (< 16 entries, in registers: lane p
+// keeps tail entry p of each of the wavefront's 16 keys); per tile the tail and the tile's new entries are compacted into one
+// lane-contiguous run through an 80-entry LDS buffer per wavefront (the new entries sit in lanes by group, with holes), the run is
+// stored up to its last line boundary -- full, aligned lines only, but for a key's very first and very last store -- and the rest
+// becomes the new tail.  Same entries at the same positions as km_write_kernel.
+__global__ __launch_bounds__(256) void km_write_lines_kernel(const uint32_t* __restrict__ table, uint64_t T, uint32_t G,
+                                                             const uint32_t* __restrict__ branch_of_group, uint32_t P,
+                                                             uint64_t slots, uint64_t* __restrict__ cursor,
+                                                             uint2* __restrict__ entries, uint64_t cap_entries)
+{
+    __shared__ uint32_t tile[64][65];
+    __shared__ uint2 work[4][80];                            // per wavefront: [tail | new entries of the key in hand]
+    if (cursor[(uint64_t)P * slots] > cap_entries) return;   // (see km_write_kernel)
+    const uint64_t x0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    size_t cidx = 0;
+    uint64_t cur = 0;
+    const bool mine = lane < 16 && x0 + wave + 4u * lane < T;
+    if (mine) {
+        const uint64_t x = x0 + wave + 4u * lane;
+        cidx = (size_t)((x % P) * slots + x / P);
+        cur = cursor[cidx];
+    }
+    uint64_t pos[16];                                        // entry index of the key's next STORE (scalar); its tail follows it
+    uint32_t tl[16];                                         // tail lengths (scalar)
+    uint32_t tbr[16], tsc[16];                               // lane p: tail entry p of key t
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur, t);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), t);
+        pos[t] = ((uint64_t)hi << 32) | lo;
+        tl[t] = 0; tbr[t] = 0; tsc[t] = 0;
+    }
+    // 16 entries = one 128-byte line; `entries` itself is at least 256-byte aligned (hipMalloc / the caching allocator)
+    uint2* const wk = work[wave];
+    const uint32_t lane8 = lane << 3;
+    const uint32_t xl = threadIdx.x & 63u;
+    const bool xok = x0 + xl < T;
+    for (uint32_t g0 = 0; g0 < G; g0 += 64) {
+        uint32_t v[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) {
+            const uint32_t gl = wave + 4u * u;
+            v[u] = 0;
+            if (g0 + gl < G && xok) v[u] = table[(size_t)(g0 + gl) * T + x0 + xl];
+        }
+        const uint32_t br = (g0 + lane < G) ? branch_of_group[g0 + lane] : 0u;
+        __syncthreads();                                     // the previous tile is consumed
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) tile[wave + 4u * u][xl] = v[u];
+        __syncthreads();
+        uint32_t wq[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) wq[t] = tile[lane][wave + 4u * (uint32_t)t];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t w = wq[t];
+            const uint64_t cm = ballot64(w != 0u);
+            const uint32_t n = (uint32_t)__popcll(cm);
+            const uint32_t tlt = tl[t];
+            const uint32_t total = tlt + n;                  // <= 15 + 64
+            // run = [tail | new entries], lane-contiguous in LDS
+            wave_lds_sync();                                 // the previous key's reads of `wk` are done
+            if (lane < tlt) wk[lane] = make_uint2(tbr[t], tsc[t]);
+            if (w != 0u) wk[tlt + mbcnt(cm)] = make_uint2(br, dec_score_bits(w));
+            wave_lds_sync();
+            // stored now: up to the last line boundary at or before the run's end
+            const uint32_t over = (uint32_t)((pos[t] + total) & 15u);
+            const uint32_t cut = over <= total ? total - over : 0u;          // (no boundary inside the run: all of it stays, total <= 15)
+            const uint32_t rem = total - cut;
+            const uint2 e0 = wk[lane], e1 = wk[min(64u + lane, 79u)], er = wk[min(cut + lane, 79u)];
+            if (cut) {
+                uint2* const d = entries + pos[t];
+                const uint64_t m0 = cut >= 64 ? ~0ull : ((1ull << cut) - 1ull);
+                store8_lanes(d, lane8, e0.x, e0.y, m0);
+                if (cut > 64) store8_lanes<512>(d, lane8, e1.x, e1.y, (1ull << (cut - 64)) - 1ull);
+            }
+            tbr[t] = er.x; tsc[t] = er.y;                    // lanes < rem: the new tail
+            tl[t] = rem;
+            pos[t] += cut;
+        }
+    }
+    // the tails leave (a key's last, partly filled line) and the cursors advance past them
+    uint64_t fin = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        if (tl[t]) store8_lanes(entries + pos[t], lane8, tbr[t], tsc[t], (1ull << tl[t]) - 1ull);
+        if (lane == (uint32_t)t) fin = pos[t] + tl[t];
+    }
+    if (mine) cursor[cidx] = fin;
+}
+
 // km_write_kernel reading the compressed form: the generic version (any number of groups; km_write_c_kernel below is the fast
 // one for up to 256 groups per batch).  Workgroup w takes key block (w % 8) * ceil(blocks / 8) + w / 8:
 // workgroups are dealt round-robin to the 8 XCDs, so each XCD walks one contiguous range of key blocks and the mask /

@@ -585,3 +585,33 @@ def test_workgroups_that_draw_their_tiles(k):
             check_against_oracle(eng, mats, groups, k, eps)          # second call: pool calibrated, no wait after pass 1
         finally:
             eng.close()
+
+
+@pytest.mark.parametrize("n_groups,world", [(70, 1), (130, 3), (5, 2)])
+def test_dense_writer_with_line_aligned_stores(n_groups, world):
+    """km_write_lines_kernel cuts every store at a 128-byte line of the output and carries the rest of a key's entries as a tail of
+    fewer than 16 (in registers, compacted with the next tile's entries through LDS); km_write_kernel (debug_flags bit 9) stores
+    tile by tile.  Same parts from both, several tiles per key (more than 64 groups), owners whose blocks start at odd offsets,
+    and a second batch appending behind the first (cursors that start in the middle of a line)."""
+    sigma, k, sites = 4, 8, 60
+    mats = synth_matrices(n_groups, sites, sigma, 0.6, 31 + n_groups)
+    groups = np.arange(n_groups, dtype=np.uint32) + 2
+    eps = co.log_threshold(1.5, sigma, k)
+    out = []
+    for flags in (0, 512):
+        eng = ipk_amd.Engine(0)
+        try:
+            eng.set_option("debug_flags", flags)
+            eng.set_option("variant", 7)                              # dense tables whatever the occupancy
+            if n_groups > 100:
+                eng.set_option("workspace_bytes", 70 * (sigma ** k) * 4)   # two batches of groups: the second appends behind the first
+            parts = eng.score_groups_keymajor(mats, groups, k, eps, n_owners=world)
+            out.append((parts.emitted, parts.counts_tensor().cpu().numpy().copy(), parts.entries_tensor().cpu().numpy().copy(),
+                        list(parts.owner_offsets)))
+            parts.free()
+        finally:
+            eng.close()
+    assert out[0][0] == out[1][0] and out[0][3] == out[1][3]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    full, emitted = _oracle_db(mats, groups, k, eps)
+    assert out[0][0] == emitted and int(out[0][1].sum()) == sum(len(v) for v in full.values())

@@ -16,6 +16,6 @@ bash tools/sweep_groups.sh 2 8 32 125 250 500 1000 > $OUT/${R}_cfg2_sweep_groups
 bash tools/prof_sq.sh ${R}_cfg2 > $OUT/${R}_cfg2_prof.log 2>&1
 bash tools/prof_sq.sh ${R}_cfg3_share --config cfg3 --groups 125 > $OUT/${R}_cfg3_prof.log 2>&1
 bash tools/prof_stats.sh ${R}_cfg4 --config cfg4 > /dev/null 2>&1
-bash tools/prof_traffic.sh ${R}_cfg2 cfg2 "score_quad_kernel reduce_buckets_kernel km_write_kernel" > $OUT/${R}_cfg2_traffic.log 2>&1
+bash tools/prof_traffic.sh ${R}_cfg2 cfg2 "score_quad_kernel reduce_buckets_kernel km_write_lines_kernel" > $OUT/${R}_cfg2_traffic.log 2>&1
 bash tools/prof_traffic.sh ${R}_cfg3_share cfg3 "score_quad_kernel reduce_buckets_kernel km_write_c_kernel" --config cfg3 --groups 125 > $OUT/${R}_cfg3_traffic.log 2>&1
 ls $OUT | grep "^${R}_" | tr '\n' ' '
