@@ -366,7 +366,8 @@ def main():
         else:
             kline(main_kernel, avg_main_ms, b_alg)
             kline("reduce_buckets_kernel", per_launch("reduce"), p_bytes + 4.0 * (sigma ** k) * ng)   # pairs in, dense tables out
-            dense_writer = "km_write_kernel" if int(os.environ.get("IPKGPU_DEBUG_FLAGS", "0")) & 512 else "km_write_lines_kernel"
+            dbg = int(os.environ.get("IPKGPU_DEBUG_FLAGS", "0"))
+            dense_writer = "km_write_kernel" if (dbg & 512) or (ng < 96 and not dbg & 1024) else "km_write_lines_kernel"
             kline(dense_writer, per_launch("km_write"), 4.0 * (sigma ** k) * ng + e_bytes)             # dense tables in, entries out
         out = {
             "metric": "scored phylo-k-mers/sec", "value": value, "unit": "phylo-k-mers/s",

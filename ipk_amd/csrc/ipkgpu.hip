@@ -2175,7 +2175,9 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
                     hipLaunchKernelGGL(km_write_c_generic_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
                                        comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
                                        ctx->offsets.as<uint64_t>(), b.entries, cap_e);
-            } else if (ctx->opt_flags & 512)                 // (debug_flags bit 9: the writer whose stores follow the tiles, not the lines)
+            } else if ((ctx->opt_flags & 512) || (gb < 96 && !(ctx->opt_flags & 1024)))
+                // (the writer whose stores follow the tiles, not the lines: for fewer than ~96 groups a key has too few entries for the
+                //  line-cut stores to repay their LDS pass -- 0.155 against 0.127 ms at 2 groups; debug_flags bit 9 forces it, bit 10 the other)
                 hipLaunchKernelGGL(km_write_kernel, dim3((uint32_t)((T + 63) / 64)), dim3(256), 0, ctx->stream,
                                    ctx->table.as<uint32_t>(), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
                                    ctx->offsets.as<uint64_t>(), b.entries, cap_e);

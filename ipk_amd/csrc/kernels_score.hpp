@@ -341,7 +341,8 @@ struct StreamParams {
                                    // bit 2 = list building only, bit 3 = quad kernel rebases its store window every 8 chunks (tests),
                                    // bit 4 = row-per-lane join: count pass only; (host) bit 5 = no first chunks by position,
                                    // (host) bit 6 = every wait of the call as in round 2 (no device-side counts, no estimated allocations),
-                                   // (host) bit 7 = fixed tile ranges, bit 8 = drawn tiles whatever the tile count (tests)
+                                   // (host) bit 7 = fixed tile ranges, bit 8 = drawn tiles whatever the tile count (tests),
+                                   // (host) bit 9 = dense key-major writer with tile-by-tile stores, bit 10 = with line-cut stores, whatever the group count
     uint32_t pre_chunks;           // row-per-lane quad kernel: chunks [0, pre_chunks) are handed out by position -- wavefront w's bucket b
                                    // starts in chunk w * NB + b -- and pool_next starts at pre_chunks (0: every first chunk is drawn)
     uint32_t* tile_next = nullptr; // quad kernel: [groups] next tile of each group -- its S workgroups DRAW their tiles instead of

@@ -598,7 +598,7 @@ def test_dense_writer_with_line_aligned_stores(n_groups, world):
     groups = np.arange(n_groups, dtype=np.uint32) + 2
     eps = co.log_threshold(1.5, sigma, k)
     out = []
-    for flags in (0, 512):
+    for flags in (1024, 512):                                         # line-cut stores whatever the group count | tile by tile
         eng = ipk_amd.Engine(0)
         try:
             eng.set_option("debug_flags", flags)
