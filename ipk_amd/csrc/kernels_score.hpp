@@ -787,14 +787,24 @@ __global__ void small_reset_kernel(uint32_t* __restrict__ small, uint32_t pre_ch
 // bit x % 32 of word x / 32 says table[x] != 0.  km_count sums these bits instead of re-reading the dense tables.
 __device__ __forceinline__ void store_slice_mask(const uint32_t* tab, uint32_t nslots, uint32_t* mask_words, uint32_t nthreads)
 {
+    // every wavefront takes a CONTIGUOUS range of 64-slot blocks and lane j keeps block j's bits, so that they leave as one coalesced
+    // 8-byte-per-lane store per 64 blocks (one lane-0 store of two words per block was 250 partly written lines per slice)
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, nwv = nthreads >> 6;
-    for (uint32_t c = wave * 64; c < nslots; c += nwv * 64) {
-        const uint32_t v = (c + lane < nslots) ? tab[c + lane] : 0u;
-        const uint64_t m = __ballot(v != 0u);
-        if (lane == 0) {                       // rows are padded to whole 64-slot blocks (mask_words = 2 * ceil(T / 64))
-            mask_words[c >> 5] = (uint32_t)m;
-            mask_words[(c >> 5) + 1] = (uint32_t)(m >> 32);
+    const uint32_t nblk = (nslots + 63) / 64;
+    const uint32_t bpw = (nblk + nwv - 1) / nwv;
+    const uint32_t b_lo = min(nblk, wave * bpw), b_hi = min(nblk, b_lo + bpw);
+    for (uint32_t b0 = b_lo; b0 < b_hi; b0 += 64) {
+        const uint32_t nb = min(64u, b_hi - b0);
+        uint64_t mine = 0;
+#pragma unroll 4
+        for (uint32_t j = 0; j < nb; ++j) {
+            const uint32_t c = (b0 + j) * 64;
+            const uint32_t v = (c + lane < nslots) ? tab[c + lane] : 0u;
+            const uint64_t m = __ballot(v != 0u);
+            if (lane == j) mine = m;
         }
+        // rows are padded to whole 64-slot blocks (mask_words = 2 * ceil(T / 64))
+        if (lane < nb) *reinterpret_cast<uint2*>(mask_words + 2 * (b0 + lane)) = make_uint2((uint32_t)mine, (uint32_t)(mine >> 32));
     }
 }
 
