@@ -55,8 +55,10 @@ def agree_on_pieces(mat_group, want, dist, device):
 
 
 def default_pieces(n_groups):
-    """Pieces a rank wishes for: a scoring call costs ~0.9 ms before its first group, so small shares are
-    not cut up for the sake of hiding the exchange -- one piece per ~48 groups, at most four (cfg2 on 8 ranks: 125 groups, 2 pieces)."""
+    """Pieces a rank wishes for: a scoring call costs ~0.5 ms before its first group (0.9 ms when this rule was
+    set), so small shares are not cut up for the sake of hiding the exchange -- one piece per ~48 groups, at most four (cfg2 on 8
+    ranks: 125 groups, 2 pieces: 2 x (0.5 + 62 x 0.02) ms of scoring with half of the exchange under the second piece; three pieces
+    would add a third 0.5 ms to hide another sixth of it)."""
     return int(min(4, max(1, n_groups // 48)))
 
 
