@@ -387,6 +387,11 @@ int ipkgpu_db_merge_files(const ipkgpu_db_header* h, const char* const* shard_pa
 const char* ipkgpu_db_merge_last_error(void);
 /* seconds of the last ipkgpu_db_write of this context: 0 = total, 1 = device packing + copies (waited for), 2 = file writes */
 double ipkgpu_db_write_time_s(const ipkgpu_ctx* ctx, int which);
+/* The protocol version the writers put behind the archive preamble, followed (after the sequence type) by the positions flag --
+ * what phylo_kmer_db::version() / positions_loaded() answer for a loaded database (tools/src/diff.cpp:41-46,137-145).  Position,
+ * width and value are guesses (ipk_format.hpp); IPKGPU_IPK_PROTOCOL_VERSION in the environment sets the value, 0 = neither field
+ * is written.  Readers of this library's files (ipkgpu_db_merge_files, the tests' parser) ask here what to expect. */
+uint32_t ipkgpu_db_protocol_version(void);
 
 #ifdef __cplusplus
 }

@@ -214,7 +214,10 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
         click.echo(f"Output: {output} ({totals[0]} k-mers, {totals[1]} entries)")
         click.echo("Note: the database layout is a reconstruction of i2l's Boost binary archive (i2l and Boost are not part of the "
                    "reference tree): UNPINNED against a real .ipk -- ipk_amd/csrc/ipk_format.hpp is the one file that knows the bytes; "
-                   "IPKGPU_BOOST_ARCHIVE_VERSION sets the archive's library version (default 19).")
+                   "IPKGPU_BOOST_ARCHIVE_VERSION sets the archive's library version (default 19).  Guessed fields: the protocol-version "
+                   "word behind the archive preamble and the positions flag behind the sequence type (position, width, value; "
+                   f"IPKGPU_IPK_PROTOCOL_VERSION, now {dbfile.protocol_version()}, 0 = both left out), the widths of the tree index "
+                   "(u64 / f64), filter value (f32) and key (u32).")
     db.free(); parts.free(); eng.close(); arp.close()
     if world > 1 and own_group:
         dist.destroy_process_group()

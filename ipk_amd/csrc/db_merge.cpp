@@ -64,6 +64,7 @@ struct ShardReader {
 extern "C" {
 
 const char* ipkgpu_db_merge_last_error(void) { return g_merge_err.c_str(); }
+uint32_t ipkgpu_db_protocol_version(void) { return ipkfmt::protocol_version(); }
 
 int ipkgpu_db_merge_files(const ipkgpu_db_header* h, const char* const* shard_paths, uint32_t n_shards, const char* path,
                           uint64_t* total_kmers, uint64_t* total_entries, uint64_t* bytes_written)

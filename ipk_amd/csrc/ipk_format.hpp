@@ -10,9 +10,21 @@
 //
 //   preamble  u64 22, "serialization::archive", u16 library version, u8 sizeof(int), u8 sizeof(long), u8 sizeof(float),
 //             u8 sizeof(double), i32 1          (basic_binary_oarchive::init + basic_binary_oprimitive::init)
-//   header    string sequence_type ; u64 n ; n x { u64 num_nodes ; f64 subtree_branch_length } ; string newick ;
+//   protocol  u32 protocol version                                            -- GUESS, see below; absent when the version is 0
+//   header    string sequence_type ; u8 positions_loaded (bool; only with the protocol word) ;
+//             u64 n ; n x { u64 num_nodes ; f64 subtree_branch_length } ; string newick ;
 //             u64 kmer_size ; f32 omega ; u64 total_num_kmers ; u64 total_num_entries
 //   k-mers    per k-mer in filter order: u32 key ; f32 filter_value ; u64 n ; n x { u32 branch ; f32 score }
+//
+// Protocol version and positions flag.  A LOADED database answers version() and positions_loaded() (the reference's own
+// ipkdiff compares both: tools/src/diff.cpp:41-46,137-145; the positions check is commented out there as "broken in v0.4.x+"),
+// and neither is an argument of phylo_kmer_db's constructor (db_builder.cpp:174) -- so both are read from the file, which the
+// seven fields of ipk_header (db_builder.cpp:297-305) alone cannot carry.  WHERE they sit and WHAT number the current protocol has
+// are not visible from the reference tree: here the version is the first word behind the Boost preamble (a reader must know it
+// before it can parse anything else) and the flag follows the sequence type (the order in which ipkdiff reports them).  Which
+// fields are guesses: the protocol word's position, width (u32) and value; the flag's position; and, as before, the archive
+// library version, u64/f64 tree index, f32 filter value and u32 key widths.  IPKGPU_IPK_PROTOCOL_VERSION=0 leaves both fields out
+// (the round-3 layout); any other value is written as given.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -37,6 +49,13 @@ inline uint16_t archive_library_version()
     if (const char* e = getenv("IPKGPU_BOOST_ARCHIVE_VERSION")) { const long v = atol(e); if (v > 0 && v < 65536) return (uint16_t)v; }
     return BOOST_ARCHIVE_LIBRARY_VERSION;
 }
+// CHANGELOG.txt counts the protocol changes (v0.2.0: three versions 2..4 by then; v0.3.0; v0.4.0; v0.5.0 "sorted by MI") -> 7
+constexpr uint32_t IPK_PROTOCOL_VERSION = 7;                // ASSUMPTION (i2l/version.h is un-vendored)
+inline uint32_t protocol_version()
+{
+    if (const char* e = getenv("IPKGPU_IPK_PROTOCOL_VERSION")) { const long v = atol(e); if (v >= 0 && v < (1l << 31)) return (uint32_t)v; }
+    return IPK_PROTOCOL_VERSION;
+}
 constexpr uint64_t RECORD_HEAD_BYTES = 16;                   // key, filter value, entry count
 constexpr uint64_t ENTRY_BYTES = 8;                          // branch, score
 
@@ -54,14 +73,18 @@ inline void put_string(std::vector<uint8_t>& o, const char* s) { const uint64_t 
 
 // everything in front of the first k-mer record
 inline std::vector<uint8_t> file_head(const char* sequence_type, uint64_t n_index, const uint32_t* num_nodes, const double* subtree_length,
-                                      const char* newick, uint64_t kmer_size, float omega, uint64_t total_kmers, uint64_t total_entries)
+                                      const char* newick, uint64_t kmer_size, float omega, uint64_t total_kmers, uint64_t total_entries,
+                                      bool positions_loaded = false)
 {
     std::vector<uint8_t> o;
     put_string(o, "serialization::archive");
     put_v<uint16_t>(o, archive_library_version());
     put_v<uint8_t>(o, 4); put_v<uint8_t>(o, 8); put_v<uint8_t>(o, 4); put_v<uint8_t>(o, 8);
     put_v<int32_t>(o, 1);
+    const uint32_t proto = protocol_version();
+    if (proto) put_v<uint32_t>(o, proto);
     put_string(o, sequence_type);
+    if (proto) put_v<uint8_t>(o, positions_loaded ? 1 : 0);
     put_v<uint64_t>(o, n_index);
     for (uint64_t i = 0; i < n_index; ++i) { put_v<uint64_t>(o, num_nodes[i]); put_v<double>(o, subtree_length[i]); }
     put_string(o, newick);
@@ -80,7 +103,8 @@ inline bool skip_string(FILE* f, uint64_t limit = (uint64_t)1 << 32)
     uint64_t n = 0;
     return get_v(f, n) && n <= limit && fseek(f, (long)n, SEEK_CUR) == 0;
 }
-// Positions `f` at the first k-mer record; the header's totals come back.  false: not a file of this layout.
+// Positions `f` at the first k-mer record; the header's totals come back.  false: not a file of this layout (as written by
+// this process: the protocol word is expected exactly when protocol_version() is non-zero, and must hold that value).
 inline bool read_head(FILE* f, uint64_t& total_kmers, uint64_t& total_entries)
 {
     uint64_t n = 0;
@@ -89,7 +113,10 @@ inline bool read_head(FILE* f, uint64_t& total_kmers, uint64_t& total_entries)
     uint16_t ver; uint8_t sz[4]; int32_t one;
     if (!get_v(f, ver) || !get(f, sz, 4) || !get_v(f, one) || sz[0] != 4 || sz[1] != 8 || sz[2] != 4 || sz[3] != 8 || one != 1) return false;
     uint64_t n_index = 0, kmer_size = 0; float omega = 0;
-    if (!skip_string(f) || !get_v(f, n_index) || n_index > ((uint64_t)1 << 32) || fseek(f, (long)(n_index * 16), SEEK_CUR) != 0) return false;
+    const uint32_t proto = protocol_version();
+    uint32_t got = 0; uint8_t positions = 0;
+    if (proto && (!get_v(f, got) || got != proto)) return false;
+    if (!skip_string(f) || (proto && (!get_v(f, positions) || positions > 1)) || !get_v(f, n_index) || n_index > ((uint64_t)1 << 32) || fseek(f, (long)(n_index * 16), SEEK_CUR) != 0) return false;
     if (!skip_string(f) || !get_v(f, kmer_size) || !get_v(f, omega)) return false;
     return get_v(f, total_kmers) && get_v(f, total_entries);
 }

@@ -14,7 +14,7 @@ import numpy as np
 from .engine import IpkGpuError, load_library
 
 ABI_SYMBOLS = ["ipkgpu_db_write", "ipkgpu_db_write_host", "ipkgpu_db_write_last_error", "ipkgpu_db_write_time_s",
-               "ipkgpu_db_merge_files", "ipkgpu_db_merge_last_error"]
+               "ipkgpu_db_merge_files", "ipkgpu_db_merge_last_error", "ipkgpu_db_protocol_version"]
 _bound = False
 
 
@@ -42,6 +42,8 @@ def _lib():
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.ipkgpu_db_merge_last_error.restype = C.c_char_p
         L.ipkgpu_db_merge_last_error.argtypes = []
+        L.ipkgpu_db_protocol_version.restype = C.c_uint32
+        L.ipkgpu_db_protocol_version.argtypes = []
         _bound = True
     return L
 
@@ -97,9 +99,17 @@ def write_db(path, sequence_type, tree_index, newick, kmer_size, omega, keys, ke
     return int(n.value)
 
 
-def read_db(path, as_arrays=False):
+def protocol_version():
+    """What the writers put behind the archive preamble (0: no protocol word, no positions flag); ipk_format.hpp."""
+    return int(_lib().ipkgpu_db_protocol_version())
+
+
+def read_db(path, as_arrays=False, protocol=None):
     """Parses the layout of ipk_format.hpp.  Returns (header dict, records): records = list of (key, filter_value, branches,
-    scores) in file order, or with as_arrays the arrays (keys, filter_values, counts, entry_offsets, branches, scores)."""
+    scores) in file order, or with as_arrays the arrays (keys, filter_values, counts, entry_offsets, branches, scores).
+    protocol: the protocol version the file was written with (None: this process' -- IPKGPU_IPK_PROTOCOL_VERSION or the default)."""
+    if protocol is None:
+        protocol = protocol_version()
     raw = np.fromfile(path, dtype=np.uint8)
     buf = raw.tobytes()
     p = 0
@@ -121,15 +131,19 @@ def read_db(path, as_arrays=False):
     lib_version = take("H")
     sizes = take("BBBB")
     assert sizes == (4, 8, 4, 8) and take("i") == 1
+    proto = take("I") if protocol else 0
+    assert proto == protocol, f"protocol word {proto}, expected {protocol}"
     st = take_string()
+    positions = bool(take("B")) if protocol else False
     ni = take("Q")
     ti = np.frombuffer(buf, dtype=[("n", "<u8"), ("l", "<f8")], count=ni, offset=p)
     p += ni * 16
     newick = take_string()
     k = take("Q"); omega = take("f"); nk = take("Q"); ne = take("Q")
     hdr = dict(sequence_type=st, tree_index=[(int(a), float(b)) for a, b in ti], newick=newick, kmer_size=k, omega=omega,
-               total_num_kmers=nk, total_num_entries=ne, library_version=lib_version)
-    body = np.frombuffer(buf, dtype="<u4", offset=p) if (len(buf) - p) % 4 == 0 else None
+               total_num_kmers=nk, total_num_entries=ne, library_version=lib_version, protocol_version=proto,
+               positions_loaded=positions)
+    body = np.frombuffer(buf[p:], dtype="<u4") if (len(buf) - p) % 4 == 0 else None
     assert body is not None and len(body) == 4 * nk + 2 * ne, "body size does not match the header's totals"
     # record starts: head of 4 words, then 2 words per entry -- walk the counts
     keys = np.empty(nk, np.uint32); fvs = np.empty(nk, np.float32); counts = np.empty(nk, np.uint64)

@@ -12,7 +12,14 @@ from oracle import db_oracle as dbo
 from oracle import ipk_oracle as co
 
 
-def test_round_trip(tmp_path):
+@pytest.mark.parametrize("protocol", [None, "0", "5"])
+def test_round_trip(tmp_path, monkeypatch, protocol):
+    """protocol: the guessed protocol-version word + positions flag (ipk_format.hpp; a loaded database answers version() and
+    positions_loaded(), tools/src/diff.cpp:41-46,137-145) -- default on, IPKGPU_IPK_PROTOCOL_VERSION=0 leaves both out."""
+    if protocol is not None:
+        monkeypatch.setenv("IPKGPU_IPK_PROTOCOL_VERSION", protocol)
+    want = 7 if protocol is None else int(protocol)
+    assert dbfile.protocol_version() == want
     sigma, k = 4, 6
     mats = synth_matrices(6, 30, sigma, 0.2, 3)
     eps = co.log_threshold(1.5, sigma, k)
@@ -25,6 +32,9 @@ def test_round_trip(tmp_path):
     dbfile.write_db(path, "DNA", [(5, 0.5), (3, 0.25), (1, 0.0)], "((A:1,B:1):1,C:2);", k, 1.5, keys, off, br,
                     sc.view(np.float32), fv, order)
     hdr, recs = dbfile.read_db(path)
+    assert hdr["protocol_version"] == want and hdr["positions_loaded"] is False
+    head_bytes = os.path.getsize(path) - 16 * len(keys) - 8 * len(br)
+    assert head_bytes == 40 + (5 if want else 0) + 8 + 3 + 8 + 3 * 16 + 8 + len("((A:1,B:1):1,C:2);") + 8 + 4 + 8 + 8
     assert hdr["sequence_type"] == "DNA" and hdr["kmer_size"] == k and hdr["total_num_kmers"] == len(keys)
     assert hdr["total_num_entries"] == len(br) and hdr["newick"].startswith("((A") and hdr["tree_index"][0] == (5, 0.5)
     assert [r[0] for r in recs] == keys[order].tolist()
@@ -33,7 +43,7 @@ def test_round_trip(tmp_path):
         assert [(int(b), int(s)) for b, s in zip(r[2], r[3].view(np.uint32))] == full[r[0]]
 
 
-def test_merge_of_rank_shards_equals_the_single_writer(tmp_path):
+def test_merge_of_rank_shards_equals_the_single_writer(tmp_path, monkeypatch):
     """Several GPUs: rank r owns the k-mers with code % P == r and its own filter values; merging the shard files by
     (filter value, key) must give the file one GPU writes (ipkgpu_db_merge_files: the role of merge_stage2,
     db_builder.cpp:392-458).  A shard is a database file in the rank's own filter order; an empty shard takes part too."""
@@ -49,6 +59,10 @@ def test_merge_of_rank_shards_equals_the_single_writer(tmp_path):
     order = np.argsort(dbfile.filter_sort_code(fv, keys), kind="stable")
     one = tmp_path / "one.db"
     dbfile.write_db(one, "DNA", [(3, 0.5)], "(a,b);", 8, 1.5, keys, off, br, sc, fv, order)
+    with monkeypatch.context() as m:                                  # a shard written under another protocol word is not this layout
+        m.setenv("IPKGPU_IPK_PROTOCOL_VERSION", "0")
+        with pytest.raises(ipk_amd.IpkGpuError):
+            dbfile.merge_shard_files(tmp_path / "x.db", "DNA", [(3, 0.5)], "(a,b);", 8, 1.5, [one])
     for world in (2, 3):
         paths = []
         for r in range(world):

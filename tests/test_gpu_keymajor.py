@@ -290,6 +290,34 @@ def test_mif0_order_matches_the_sequential_oracle(engine):
     db.free(); parts.free()
 
 
+@pytest.mark.parametrize("protocol", [None, "0"])
+def test_device_writer_and_host_writer_write_the_same_bytes(engine, tmp_path, monkeypatch, protocol):
+    """ipkgpu_db_write (records packed on the device, streamed) against ipkgpu_db_write_host over the same shard, with and
+    without the guessed protocol-version word / positions flag (ipk_format.hpp); both parse back to the shard."""
+    import ipk_amd
+    from ipk_amd import dbfile
+    if protocol is not None:
+        monkeypatch.setenv("IPKGPU_IPK_PROTOCOL_VERSION", protocol)
+    sigma, k, n_groups = 4, 7, 5
+    mats = synth_matrices(n_groups * 2, 120, sigma, 0.1, 4242)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 2, 2)
+    eps = co.log_threshold(1.5, sigma, k)
+    db, parts = D.build_db_shard(engine, mats, groups, k, eps, sigma)
+    db.filter_mif0(engine, n_groups + 1, ipk_amd.score_threshold(1.5, sigma, k))
+    ti = [(5, 0.5), (1, 0.0)]
+    dev, host = tmp_path / "dev.ipk", tmp_path / "host.ipk"
+    n = dbfile.write_db_device(engine, db, dev, "DNA", ti, "(a:1,b:2);", k, 1.5)
+    b, s = db.entries()
+    dbfile.write_db(host, "DNA", ti, "(a:1,b:2);", k, 1.5, db.keys(), db.key_offsets(), b, s, db.filter_values(), db.filter_order())
+    raw = open(dev, "rb").read()
+    assert n == len(raw) and raw == open(host, "rb").read()
+    hdr, (keys, fvs, counts, eoff, br, sc) = dbfile.read_db(dev, as_arrays=True)
+    assert hdr["protocol_version"] == (7 if protocol is None else 0) and hdr["total_num_kmers"] == db.num_keys
+    order = db.filter_order()
+    assert np.array_equal(keys, db.keys()[order]) and np.array_equal(fvs.view(np.uint32), db.filter_values()[order].view(np.uint32))
+    db.free(); parts.free()
+
+
 def test_native_exchange_single_rank_comm():
     """The in-library RCCL exchange (ipkgpu_comm_init / ipkgpu_exchange_begin / ipkgpu_exchange_merge) on a one-rank
     communicator -- all a one-GPU box can run: sizes and payload travel rank 0 -> rank 0 through grouped ncclSend/ncclRecv,
