@@ -61,7 +61,9 @@ def ipk():
                    "the kept score's window position) but only with per-branch output; the database of positioned entries -- "
                    "i2l's positioned phylo_kmer and its serialisation, un-vendored -- has no container here, so no file could be written.")
 @click.option("--uncompressed", is_flag=True, help="(ignored, as in the reference)")
-@click.option("--threads", type=int, default=1, show_default=True, help="host threads of the probability loader")
+@click.option("--threads", type=int, default=0,
+              help="host threads of the probability loader [0 = every core this process may run on, divided among the ranks of a node; the reference's --threads only "
+                   "feeds the AR tool (ar.cpp:669,749), which this command does not run]")
 @click.option("-o", "--output", default=None, help="output file [workdir/DB.ipk]")
 @click.option("--on-disk", is_flag=True, help="(ignored: the GPU build batches groups by HBM instead)")
 @click.option("--mapping", type=click.Path(exists=True), default=None,
@@ -157,7 +159,7 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
 
     t0 = time.time()
     arp = AncestralProbs(probs_file, sigma)
-    mats = arp.read(labels, n_threads=max(1, threads)) if labels else np.zeros((0, arp.sites, sigma), np.float32)
+    mats = arp.read(labels, n_threads=threads if threads > 0 else max(1, len(os.sched_getaffinity(0)) // world)) if labels else np.zeros((0, arp.sites, sigma), np.float32)
     t_load = time.time() - t0
     log_eps = ipk_amd.log_threshold(omega, sigma, k)
     eng = ipk_amd.Engine(device)

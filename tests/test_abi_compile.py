@@ -40,6 +40,29 @@ def test_integration_stubs_compile_link_and_refuse_without_a_gpu(tmp_path):
 
 @pytest.mark.gpu
 def test_integration_stub_runs_on_the_gpu(tmp_path):
+    """The db_builder patch of INTEGRATION.md, compiled, fills the (mock) database on the GPU; what it inserted -- scored count and
+    every (key, branch, score bits) triple -- is compared with the oracle run on the very same matrices (the stub dumps them)."""
+    import numpy as np
+    from oracle import ipk_oracle as co
     exe = _build(tmp_path)
-    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    dump = tmp_path / "mats.f32"
+    r = subprocess.run([str(exe), str(dump)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "groups 3" in r.stdout, (r.stdout, r.stderr)
+    m = re.search(r"scored (\d+) kmers (\d+) entries (\d+) eps ([0-9a-f]{8}) fnv ([0-9a-f]{16})", r.stdout)
+    assert m, r.stdout
+    mats = np.fromfile(dump, dtype=np.float32).reshape(6, 60, 4)
+    eps = np.array([int(m.group(4), 16)], dtype=np.uint32).view(np.float32)[0]
+    assert eps == np.float32(co.log_threshold(1.5, 4, 8))
+    triples, scored = [], 0
+    for g in range(3):
+        keys, scores, emitted = co.explore_group(mats[2 * g:2 * g + 2], 8, float(eps))
+        scored += emitted
+        triples += [(int(k), 7 + g, int(s)) for k, s in zip(keys, scores.view(np.uint32))]
+    triples.sort()
+    fnv = 1469598103934665603
+    for t in triples:
+        for w in t:
+            for i in range(4):
+                fnv = ((fnv ^ ((w >> (8 * i)) & 0xFF)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert int(m.group(1)) == scored and int(m.group(3)) == len(triples) and int(m.group(2)) == len({t[0] for t in triples})
+    assert int(m.group(5), 16) == fnv

@@ -111,6 +111,29 @@ def test_flat_columns_ties(engine):
     check_against_oracle(engine, mats, [0, 0], 6, co.log_threshold(1.0, 4, 6))
 
 
+def _zero_tie_group():
+    """Two matrices of one group whose only scored k-mer (code 0) scores -0.0 in the first and +0.0 in the second."""
+    ninf = -np.inf
+    first = np.tile(np.array([-0.0, ninf, ninf, ninf], np.float32), (12, 1))
+    second = np.tile(np.array([0.0, ninf, ninf, ninf], np.float32), (12, 1))
+    return np.stack([first, second])
+
+
+def test_negative_zero_tie(engine):
+    """The ONE documented deviation from `put` (branch_group.cpp:88-101: replace only if the stored score < the new one, so of
+    -0.0 then +0.0 -- equal as floats -- the reference keeps the first, -0.0): the engine's max runs on an order-preserving
+    integer code in which +0.0 is above -0.0, so it keeps +0.0 whatever the order.  Equal values, one bit apart."""
+    eps = co.log_threshold(1.5, 4, 6)
+    for mats, oracle_bits in ((_zero_tie_group(), 0x80000000), (_zero_tie_group()[::-1].copy(), 0x00000000)):
+        keys, scores, emitted = co.explore_group(mats, 6, eps)
+        assert keys.tolist() == [0] and scores.view(np.uint32).tolist() == [oracle_bits]       # the oracle follows put: first wins
+        res = engine.score_groups(mats, np.array([5, 5], np.uint32), 6, eps)
+        gk, gs = res.group(0)
+        assert gk.tolist() == [0] and res.emitted == emitted
+        assert gs[0] == scores[0] and gs.view(np.uint32).tolist() == [0x00000000]               # the engine: +0.0 either way
+        res.free()
+
+
 def test_idempotent_and_sorted(engine):
     mats = synth_matrices(6, 500, 4, 0.05, 31)
     groups = [0, 0, 1, 1, 2, 2]
