@@ -36,6 +36,7 @@
 #include "kernels_quad.hpp"
 #include "kernels_compact.hpp"
 #include "kernels_keymajor.hpp"
+#include "kernels_reduce_pipe.hpp"
 #include "kernels_filter.hpp"
 #include "kernels_dbfile.hpp"
 #include <chrono>
@@ -550,6 +551,9 @@ int launch_stream_overflow(ipkgpu_ctx* ctx, const StreamParams& sp)
     }
 }
 
+#ifndef IPK_RPIPE_D
+#define IPK_RPIPE_D 4            // chunks per trip of the persistent reduce (two trips of D * 4 eight-byte loads per lane in flight)
+#endif
 template <int SIGMA, int K>
 int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* table, bool compress)
 {
@@ -558,7 +562,7 @@ int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* ta
     else {
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
         constexpr int NT = TBL <= 16384 ? 512 : 1024;
-        const size_t lds = (size_t)TBL * 4 + (compress ? (NT / 64 + 1) * 4 : 0);
+        const size_t lds = compress ? (size_t)comp_padded_slots<TBL, NT>() * 4 + (NT / 64 + 1) * 4 : (size_t)TBL * 4;
         auto launch = [&](auto kern) -> int {
             if (lds > 64 * 1024)
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -568,6 +572,20 @@ int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* ta
             HIP_TRY(ctx, hipGetLastError());
             return IPKGPU_OK;
         };
+        // 128-KB slices (DNA k = 11, 12) leave one workgroup per CU: the persistent, pipelined form (kernels_reduce_pipe.hpp);
+        // debug_flags bit 11 keeps the workgroup-per-slice kernel (tests compare the two)
+        if constexpr (TBL * 4 > 80 * 1024) {
+            if (compress && (ctx->opt_flags & 2048)) {   // (opt-in until measured)
+                constexpr int PD = IPK_RPIPE_D;
+                auto kern = reduce_buckets_pipe_kernel<TBL, NT, PD>;
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(n_gb, (uint32_t)ctx->num_cu)), dim3(NT), lds, ctx->stream, ctx->pool.as<uint2>(),
+                                   ctx->gboff.as<uint64_t>(), ctx->clist.as<uint2>(), n_gb, NB, T, ctx->mask.as<uint32_t>(), ctx->mask_words,
+                                   ctx->cvals.as<uint2>(), ctx->coff.as<uint64_t>(), ctx->rank.as<uint32_t>(), ctx->vaddr.as<uint64_t>(), ctx->ucnt.as<uint32_t>());
+                HIP_TRY(ctx, hipGetLastError());
+                return IPKGPU_OK;
+            }
+        }
         return compress ? launch(reduce_buckets_kernel<TBL, NT, true>) : launch(reduce_buckets_kernel<TBL, NT, false>);
     }
 }
@@ -715,7 +733,7 @@ int launch_xp_reduce(ipkgpu_ctx* ctx, uint32_t n_gb, uint32_t S, uint64_t T, con
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
         static_assert(!COMPRESS || NB == 1 || TBL % 64 == 0, "a 64-slot block must not straddle two buckets");
         constexpr int NT = TBL <= 16384 ? 512 : 1024;       // (16000-slot tables: 1024 threads measure the same 16.5 ms as 512 since the coalesced epilogue, 256 are slower: 22.3)
-        constexpr size_t lds = (size_t)TBL * 4 + (COMPRESS ? (NT / 64 + 1) * 4 : 0);
+        constexpr size_t lds = COMPRESS ? (size_t)comp_padded_slots<TBL, NT>() * 4 + (NT / 64 + 1) * 4 : (size_t)TBL * 4;
         auto kern = reduce_ranges_kernel<TBL, NT, COMPRESS>;
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

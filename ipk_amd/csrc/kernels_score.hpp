@@ -824,48 +824,77 @@ __global__ __launch_bounds__(256) void comp_slice_room_kernel(const uint32_t* __
 }
 
 // The compressed form of a finished table slice (comp_table.hpp): occupancy bits, rank of every 64-slot block, the non-empty
-// slots' score codes in slot order at `vals`, and the blocks' value addresses.  `tab` = the slice in LDS (TBL slots, then room for
-// NT / 64 + 1 words); every thread of the workgroup calls it after the barrier that ends the reduction.
-template <uint32_t TBL, int NT>
+// slots' score codes in slot order at `vals`, and the blocks' value addresses.  `tab` = the slice in LDS, PADDED to
+// comp_padded_slots<TBL, NT>() slots (every wavefront owns exactly BPW whole blocks; the slots past the slice are zero and stay zero:
+// no key maps there), then NT / 64 + 1 words; every thread of the workgroup calls it after the barrier that ends the reduction.
+//
+// Round 4: this epilogue was most of the reduce kernels' vector instructions (r04_*_backhalf_sq.json: 960 VALU per wavefront and
+// slice at AA k = 6, of which 775 here -- 24 per 64-slot block -- with the SIMDs' vector pipes 83 % busy), so it is written for
+// instruction count: no bounds tests (padding), block addresses as immediate LDS offsets, the per-block rank and bits gathered with
+// v_writelane (one instruction per value, no compare), the value stores as scalar base + 32-bit lane offset.  ZERO: the slots are
+// cleared on the way out (the persistent kernel's next slice starts from a clean table; needs a barrier before the next atomics).
+// v_writelane_b32 with the lane as an immediate: lane LANE of v := the wave-uniform value s (no builtin in this compiler)
+template <uint32_t LANE>
+__device__ __forceinline__ void writelane_imm(uint32_t& v, uint32_t s)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+}
+template <uint32_t N, class F, uint32_t... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<uint32_t, I...>) { (f(std::integral_constant<uint32_t, I>{}), ...); }
+template <uint32_t N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<uint32_t, N>{}); }
+
+template <uint32_t TBL, int NT> constexpr uint32_t comp_bpw() { return ((TBL + 63) / 64 + NT / 64 - 1) / (NT / 64); }
+template <uint32_t TBL, int NT> constexpr uint32_t comp_padded_slots() { return comp_bpw<TBL, NT>() * (NT / 64) * 64; }
+// REREAD: the blocks are read from LDS a second time for the write-out instead of being kept in registers (the persistent kernel has
+// 64 registers of pair loads in flight through here).
+template <uint32_t TBL, int NT, bool ZERO = false, bool REREAD = false>
 __device__ __forceinline__ void compress_slice(uint32_t* tab, uint32_t nslots, uint32_t* vals, uint32_t* mrow, uint32_t* rrow,
                                                uint64_t* arow, uint32_t* ucnt_gb)
 {
-    // every wave owns a contiguous range of 64-slot blocks: totals per wave, then each wave runs its own offsets
-    constexpr uint32_t NWV = NT / 64, MAXBLK = (TBL + 63) / 64, BPW = (MAXBLK + NWV - 1) / NWV;
-    uint32_t* wtot = tab + TBL;                                   // [NWV + 1]
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    constexpr uint32_t NWV = NT / 64, BPW = comp_bpw<TBL, NT>(), PAD = comp_padded_slots<TBL, NT>();
+    static_assert(BPW <= 64, "one lane per block of the wave");
+    uint32_t* wtot = tab + PAD;                                   // [NWV + 1]
+    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t nblk = (nslots + 63) / 64;
-    const uint32_t b_lo = min(nblk, wave * BPW), b_hi = min(nblk, b_lo + BPW);
+    uint32_t* wb = tab + wave * (BPW * 64) + lane;                // block j of this wavefront: wb[j * 64]
     // the wave's blocks in registers (all LDS reads in flight together), then counting and writing run on registers
-    uint32_t vr[BPW];
+    uint32_t vr[REREAD ? 1 : BPW];
     uint32_t mine = 0;
+    if constexpr (REREAD) {
 #pragma unroll
-    for (uint32_t j = 0; j < BPW; ++j) {
-        const uint32_t z = (b_lo + j) * 64 + lane;
-        vr[j] = (b_lo + j < b_hi && z < nslots) ? tab[z] : 0u;
+        for (uint32_t j = 0; j < BPW; ++j) mine += (uint32_t)__popcll(__ballot(wb[j * 64] != 0u));
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < BPW; ++j) vr[j] = wb[j * 64];
+#pragma unroll
+        for (uint32_t j = 0; j < BPW; ++j) mine += (uint32_t)__popcll(__ballot(vr[j] != 0u));
     }
-#pragma unroll
-    for (uint32_t j = 0; j < BPW; ++j) mine += (uint32_t)__popcll(__ballot(vr[j] != 0u));
     if (lane == 0) wtot[wave] = mine;
     __syncthreads();
     uint32_t base = 0, all = 0;
-    for (uint32_t w = 0; w < NWV; ++w) { const uint32_t t = wtot[w]; if (w < wave) base += t; all += t; }
-    // lane j collects block j's rank and bits; they leave as coalesced stores after the loop (BPW <= 64)
-    static_assert(BPW <= 64, "one lane per block of the wave");
-    uint32_t my_base = 0;
-    uint64_t my_m = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < BPW; ++j) {
-        const uint32_t blk = b_lo + j;
-        const uint64_t m = __ballot(vr[j] != 0u);
-        if (lane == j) { my_base = base; my_m = m; }
-        if (blk < b_hi && vr[j] != 0u) vals[base + mbcnt(m)] = vr[j];
+    for (uint32_t w = 0; w < NWV; ++w) { const uint32_t t = wtot[w]; if (w < wave) base += t; all += t; }
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    // lane j collects block j's rank and bits; they leave as coalesced stores after the loop
+    uint32_t my_base = 0, my_lo = 0, my_hi = 0;
+    char* vbytes = reinterpret_cast<char*>(vals);
+    static_for<BPW>([&](auto J) {
+        constexpr uint32_t j = decltype(J)::value;
+        uint32_t v;
+        if constexpr (REREAD) v = wb[j * 64]; else v = vr[j];
+        const uint64_t m = __ballot(v != 0u);
+        writelane_imm<j>(my_base, base);
+        writelane_imm<j>(my_lo, (uint32_t)m);
+        writelane_imm<j>(my_hi, (uint32_t)(m >> 32));
+        if (v != 0u) *reinterpret_cast<uint32_t*>(vbytes + ((base + mbcnt(m)) << 2)) = v;
+        if constexpr (ZERO) wb[j * 64] = 0u;
         base += (uint32_t)__popcll(m);
-    }
-    if (b_lo + lane < b_hi) {
-        const uint32_t blk = b_lo + lane;
+    });
+    const uint32_t blk = wave * BPW + lane;
+    if (lane < BPW && blk < nblk) {
         rrow[blk] = my_base;
-        *reinterpret_cast<uint2*>(mrow + 2 * blk) = make_uint2((uint32_t)my_m, (uint32_t)(my_m >> 32));
+        *reinterpret_cast<uint2*>(mrow + 2 * blk) = make_uint2(my_lo, my_hi);
         arow[blk] = (uint64_t)(vals + my_base);
     }
     if (threadIdx.x == 0) *ucnt_gb = all;
@@ -899,7 +928,8 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
     uint2 e0 = make_uint2(0, 0), e1 = make_uint2(0, 0);
     if (ci < c1) e0 = list[ci];
     if (ci + NWV < c1) e1 = list[ci + NWV];
-    for (uint32_t i = threadIdx.x; i < TBL / 4; i += NT) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0, 0, 0, 0);
+    constexpr uint32_t CLR = COMPRESS ? comp_padded_slots<TBL, NT>() : TBL;      // (the compress epilogue reads whole blocks per wavefront)
+    for (uint32_t i = threadIdx.x; i < CLR / 4; i += NT) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t k0 = (uint32_t)key0;
     while (ci < c1) {
@@ -1387,7 +1417,8 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(uint2* __restrict__ p
     uint64_t i = r0 + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < PER; ++j) if (i + (uint64_t)j * NT < r1) v[j] = pool[i + (uint64_t)j * NT];   // in flight while the table is cleared
-    for (uint32_t z = threadIdx.x; z < TBL / 4; z += NT) reinterpret_cast<uint4*>(tab)[z] = make_uint4(0, 0, 0, 0);
+    constexpr uint32_t CLR = COMPRESS ? comp_padded_slots<TBL, NT>() : TBL;      // (the compress epilogue reads whole blocks per wavefront)
+    for (uint32_t z = threadIdx.x; z < CLR / 4; z += NT) reinterpret_cast<uint4*>(tab)[z] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t k0 = (uint32_t)key0;
     while (i < r1) {
