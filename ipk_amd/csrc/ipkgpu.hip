@@ -551,8 +551,11 @@ int launch_stream_overflow(ipkgpu_ctx* ctx, const StreamParams& sp)
     }
 }
 
+#ifndef IPK_RPIPE_DEFAULT
+#define IPK_RPIPE_DEFAULT 1
+#endif
 #ifndef IPK_RPIPE_D
-#define IPK_RPIPE_D 4            // chunks per trip of the persistent reduce (two trips of D * 4 eight-byte loads per lane in flight)
+#define IPK_RPIPE_D 2            // chunks per trip of the persistent reduce (two trips of D * 4 eight-byte loads per lane in flight)
 #endif
 template <int SIGMA, int K>
 int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* table, bool compress)
@@ -572,10 +575,11 @@ int launch_stream_pass2(ipkgpu_ctx* ctx, uint32_t n_gb, uint64_t T, uint32_t* ta
             HIP_TRY(ctx, hipGetLastError());
             return IPKGPU_OK;
         };
-        // 128-KB slices (DNA k = 11, 12) leave one workgroup per CU: the persistent, pipelined form (kernels_reduce_pipe.hpp);
-        // debug_flags bit 11 keeps the workgroup-per-slice kernel (tests compare the two)
+        // 128-KB slices (DNA k = 11, 12) leave one workgroup per CU: the persistent, pipelined form (kernels_reduce_pipe.hpp; cfg3
+        // share: 2.72-2.85 ms against 3.03-3.07 for the workgroup-per-slice kernel); debug_flags bit 11 switches to the other of the
+        // two (tests compare them)
         if constexpr (TBL * 4 > 80 * 1024) {
-            if (compress && (ctx->opt_flags & 2048)) {   // (opt-in until measured)
+            if (compress && ((IPK_RPIPE_DEFAULT != 0) != ((ctx->opt_flags & 2048) != 0))) {
                 constexpr int PD = IPK_RPIPE_D;
                 auto kern = reduce_buckets_pipe_kernel<TBL, NT, PD>;
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1476,7 +1480,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         // descriptors of this batch's chunks were all written by pass 1 (closed or flushed), stale ones are overwritten
         // or lie beyond n_used.
         HIP_TRY(ctx, hipMemsetAsync(ctx->gbcnt.p, 0, 2 * n_gb * 4, ctx->stream));
-        RC_TRY(ensure(ctx, ctx->clist, std::max<uint64_t>(n_used, 1) * 8));
+        RC_TRY(ensure(ctx, ctx->clist, ((uint64_t)n_used + 16) * 8));   // (+16: the persistent reduce fetches a trip's descriptors with one scalar load)
         if (s_compress) {
             RC_TRY(ensure(ctx, ctx->croom, 2 * n_gb * 4));                  // [pairs per (group, bucket) | room of its values]
             HIP_TRY(ctx, hipMemsetAsync(ctx->croom.p, 0, n_gb * 4, ctx->stream));

@@ -443,6 +443,9 @@ __device__ __forceinline__ uint32_t dec_score_bits_bf(uint32_t e) { return e ^ ~
 #ifndef IPK_KMC_VB
 #define IPK_KMC_VB 8
 #endif
+#ifndef IPK_KMC_RL
+#define IPK_KMC_RL 1             // a row's bits and value address by v_readlane (1) or by a 16-byte broadcast LDS read (0) in the value-load phase
+#endif
 constexpr uint32_t KMC_CAP = IPK_KMC_CAP;   // entries of a key block staged in LDS at once (33 KiB + 6 KiB of row data: four workgroups per CU.
                                             // While the kernel needed 150+ VGPRs -- three wavefronts per SIMD -- a smaller stage bought nothing
                                             // (3840 / 2816: equal at a cfg3 share, 13-17 % slower at cfg4); at 113 VGPRs 4224 is 2-3 % ahead of 5632
@@ -532,6 +535,26 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
     // key that has one (or, past the row's end, whatever follows it in the pool, which is allocated 256 B longer for this) and
     // does not store it.
     uint32_t val[64];
+    const uint32_t rm_lo = (uint32_t)row_m, rm_hi = (uint32_t)(row_m >> 32), ra_lo = (uint32_t)row_va, ra_hi = (uint32_t)(row_va >> 32);
+#if IPK_KMC_RL
+    // (round 4: a row's bits and value address reach the lanes by v_readlane from the lane-per-row registers, not by a 16-byte
+    //  broadcast read -- r04_cfg4_backhalf_sq.json has the LDS pipe busy 85 % of this kernel's time, and of a row's ~18 LDS cycles
+    //  eight were that read: 64 lanes x 16 bytes come back through the LDS data path whether the address is shared or not)
+#pragma unroll
+    for (uint32_t b8 = 0; b8 < 64; b8 += 8) {
+        if (b8 < nrows) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t r = b8 + u;
+                const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)rm_lo, (int)r), mhi = (uint32_t)__builtin_amdgcn_readlane((int)rm_hi, (int)r);
+                const uint32_t alo = (uint32_t)__builtin_amdgcn_readlane((int)ra_lo, (int)r), ahi = (uint32_t)__builtin_amdgcn_readlane((int)ra_hi, (int)r);
+                const uint32_t j = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                const global_u32_ptr vals = (global_u32_ptr)(((uint64_t)ahi << 32) | alo);
+                val[r] = __builtin_nontemporal_load(vals + j);
+            }
+        }
+    }
+#else
 #pragma unroll
     for (uint32_t b8 = 0; b8 < 64; b8 += 8) {
         if (b8 < nrows) {
@@ -552,6 +575,7 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
             }
         }
     }
+#endif
     __syncthreads();
     const uint32_t out_lds = lds_address(out);
 
@@ -580,7 +604,15 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
                         uint2 mmq[SB]; uint32_t brq[SB];
                         asm volatile("" ::: "memory");                   // (fresh reads: reusing the value-load phase's copies would keep 128 registers alive)
 #pragma unroll
-                        for (uint32_t u = 0; u < SB; ++u) { mmq[u] = *reinterpret_cast<const uint2*>(&rowmeta[wave][b8 + b4 + u]); brq[u] = rowbr[wave][b8 + b4 + u]; }
+                        for (uint32_t u = 0; u < SB; ++u) {
+#if IPK_KMC_RL
+                            mmq[u] = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rm_lo, (int)(b8 + b4 + u)),
+                                                (uint32_t)__builtin_amdgcn_readlane((int)rm_hi, (int)(b8 + b4 + u)));     // (no LDS read: see the value-load phase)
+#else
+                            mmq[u] = *reinterpret_cast<const uint2*>(&rowmeta[wave][b8 + b4 + u]);
+#endif
+                            brq[u] = rowbr[wave][b8 + b4 + u];
+                        }
 #pragma unroll
                         for (uint32_t u = 0; u < SB; ++u) {
                             uint2 mm = mmq[u];

@@ -61,6 +61,13 @@ __global__ __launch_bounds__(NT) void reduce_buckets_pipe_kernel(const uint2* __
     // the descriptors (chunk id, pairs) of the D chunks of a trip: one scalar load (the list is padded by D entries)
     struct Desc { uint2 e[D]; };
     static_assert(D == 2 || D == 4 || D == 8, "a trip's descriptors are one s_load_dwordx{4,8,16}");
+    auto load_desc = [&](uint32_t idx) {                     // (adjacent scalar loads: merged into one)
+        Desc d;
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(list + idx);
+#pragma unroll
+        for (int j = 0; j < D; ++j) { const uint64_t w = uniform_load(p + j); d.e[j] = make_uint2((uint32_t)w, (uint32_t)(w >> 32)); }
+        return d;
+    };
 
     uint32_t cur = 0, lpos = 0, cstart, ccnt;                // load cursor: slice cur, chunk lpos of this wavefront's share [cstart, + ccnt)
     Meta mcur = load_meta(0), mnext = load_meta(1), min2 = load_meta(2);
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(NT) void reduce_buckets_pipe_kernel(const uint2* __
     // the NEXT trip: its descriptors are requested one trip ahead (kind: 0 = nothing, the cursor is past the last slice; 1 = chunks
     // of a slice; 2 = ... and the share's last ones, possibly none)
     uint32_t ntake = min((uint32_t)D, ccnt), nkind = ccnt <= (uint32_t)D ? 2u : 1u;
-    Desc nd = uniform_load(reinterpret_cast<const Desc*>(list + cstart));
+    Desc nd = load_desc(cstart);
     uint64_t cv = load_cv(0), cvn = load_cv(1);              // offsets of this slice's values, of the next one's
 
     uint32_t it = 0;                                         // the slice being reduced
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(NT) void reduce_buckets_pipe_kernel(const uint2* __
         if (kind != 0 && cur < n_items) {
             ntake = min((uint32_t)D, ccnt - lpos);
             nkind = lpos + ntake >= ccnt ? 2u : 1u;
-            nd = uniform_load(reinterpret_cast<const Desc*>(list + cstart + lpos));
+            nd = load_desc(cstart + lpos);
         } else {
             ntake = 0; nkind = 0;
         }
@@ -134,15 +141,19 @@ __global__ __launch_bounds__(NT) void reduce_buckets_pipe_kernel(const uint2* __
     uint32_t kA = fill(PA, pcA), kB = fill(PB, pcB);
     for (uint32_t i = threadIdx.x; i < PAD / 4; i += NT) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    // (the loop is rotated -- its head is a fill, not a consume: the compiler's wait-count pass is exact inside straight-line code but
+    //  falls back to "nothing newer is in flight" for registers consumed right at a loop head, which would wait for BOTH trips)
+    consume(PA, pcA);
+    bool endA = kA == 2;
     for (;;) {
-        consume(PA, pcA);
-        const bool endA = kA == 2;
         kA = fill(PA, pcA);
         if (endA) { boundary(); if (it >= n_items) break; }
         consume(PB, pcB);
         const bool endB = kB == 2;
         kB = fill(PB, pcB);
         if (endB) { boundary(); if (it >= n_items) break; }
+        consume(PA, pcA);
+        endA = kA == 2;
     }
 }
 

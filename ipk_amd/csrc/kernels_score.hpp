@@ -833,11 +833,27 @@ __global__ __launch_bounds__(256) void comp_slice_room_kernel(const uint32_t* __
 // instruction count: no bounds tests (padding), block addresses as immediate LDS offsets, the per-block rank and bits gathered with
 // v_writelane (one instruction per value, no compare), the value stores as scalar base + 32-bit lane offset.  ZERO: the slots are
 // cleared on the way out (the persistent kernel's next slice starts from a clean table; needs a barrier before the next atomics).
+#ifndef IPK_RB_ABL
+#define IPK_RB_ABL 0             // timing experiments (results wrong, every address stays valid): 1 = no pair loads, 2 = no LDS atomics, 4 = no value stores in the compress epilogue
+#endif
+#ifndef IPK_COMPACT
+#define IPK_COMPACT 0            // compress epilogue, 1: values compacted in LDS per wavefront and copied out as full-wave stores -- measured SLOWER than
+                                 // one partial store per 64-slot block (cfg3 share 3.26 against 3.03 ms, cfg4 14.0 against 13.8): the runs merge in L2 anyway
+#endif
 // v_writelane_b32 with the lane as an immediate: lane LANE of v := the wave-uniform value s (no builtin in this compiler)
 template <uint32_t LANE>
-__device__ __forceinline__ void writelane_imm(uint32_t& v, uint32_t s)
+__device__ __forceinline__ void writelane_imm(uint32_t& v, uint32_t s)       // (s_nop: see writelane64_imm; s may come from v_readfirstlane)
 {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+}
+// both halves of a 64-bit wave-uniform value (a ballot: written by a VALU compare).  gfx950 needs two wait states between a VALU
+// write of an SGPR and a VALU read of it; the compiler pads its own instructions but cannot see into an asm statement -- without
+// the s_nop the v_writelane right behind the v_cmp picked up the PREVIOUS block's bits (keys 64 slots off).
+template <uint32_t LANE>
+__device__ __forceinline__ void writelane64_imm(uint32_t& vlo, uint32_t& vhi, uint64_t s)
+{
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(vlo), "+v"(vhi) : "s"((uint32_t)s), "s"((uint32_t)(s >> 32)), "n"(LANE));
 }
 template <uint32_t N, class F, uint32_t... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<uint32_t, I...>) { (f(std::integral_constant<uint32_t, I>{}), ...); }
@@ -879,18 +895,46 @@ __device__ __forceinline__ void compress_slice(uint32_t* tab, uint32_t nslots, u
     // lane j collects block j's rank and bits; they leave as coalesced stores after the loop
     uint32_t my_base = 0, my_lo = 0, my_hi = 0;
     char* vbytes = reinterpret_cast<char*>(vals);
+    if constexpr (IPK_COMPACT != 0) {
+        // The wavefront's values are compacted IN PLACE at the head of its own table region (block j's values land at or below
+        // block j's slots, which are in registers or already read), then leave as full-wave stores of 64 consecutive values --
+        // r04 ablation: the per-block stores (a run of ~20 values at 4-byte alignment each) were 0.5 of 3.0 ms at a cfg3 share
+        // and 2.75 of 13.5 ms at cfg4.  No barrier: every wavefront stays inside its own region.
+        uint32_t* wreg = tab + wave * (BPW * 64);
+        uint32_t lp = 0;
+        static_for<BPW>([&](auto J) {
+            constexpr uint32_t j = decltype(J)::value;
+            uint32_t v;
+            if constexpr (REREAD) v = wb[j * 64]; else v = vr[j];
+            const uint64_t m = __ballot(v != 0u);
+            writelane_imm<j>(my_base, base + lp);
+            writelane64_imm<j>(my_lo, my_hi, m);
+            if (v != 0u) wreg[lp + mbcnt(m)] = v;
+            lp += (uint32_t)__popcll(m);
+        });
+        uint32_t* dst = vals + base;
+        for (uint32_t t = lane; t < lp; t += 64) {
+            const uint32_t v = wreg[t];
+            if (!(IPK_RB_ABL & 4) || v == 0xFFFFFFFEu) dst[t] = v;
+        }
+        if constexpr (ZERO) {
+            // (everything the wavefront's region may hold: compacted values at the head, blocks not yet overwritten behind them)
+#pragma unroll
+            for (uint32_t j = 0; j < BPW; ++j) wb[j * 64] = 0u;
+        }
+    } else {
     static_for<BPW>([&](auto J) {
         constexpr uint32_t j = decltype(J)::value;
         uint32_t v;
         if constexpr (REREAD) v = wb[j * 64]; else v = vr[j];
         const uint64_t m = __ballot(v != 0u);
         writelane_imm<j>(my_base, base);
-        writelane_imm<j>(my_lo, (uint32_t)m);
-        writelane_imm<j>(my_hi, (uint32_t)(m >> 32));
-        if (v != 0u) *reinterpret_cast<uint32_t*>(vbytes + ((base + mbcnt(m)) << 2)) = v;
+        writelane64_imm<j>(my_lo, my_hi, m);
+        if ((IPK_RB_ABL & 4) ? v == 0xFFFFFFFEu : v != 0u) *reinterpret_cast<uint32_t*>(vbytes + ((base + mbcnt(m)) << 2)) = v;
         if constexpr (ZERO) wb[j * 64] = 0u;
         base += (uint32_t)__popcll(m);
     });
+    }
     const uint32_t blk = wave * BPW + lane;
     if (lane < BPW && blk < nblk) {
         rrow[blk] = my_base;
@@ -904,6 +948,10 @@ __device__ __forceinline__ void compress_slice(uint32_t* tab, uint32_t nslots, u
 // sparsely (DNA k = 12: 38 % of a group's 16.8 M slots at cfg3) the dense tables are the larger part of what pass 2 writes and
 // the key-major writer reads.  The values of (group, bucket) go to cvals + coff[group * NB + bucket] (8-byte units; room for
 // min(pairs, slots) values each, comp_slice_room_kernel).
+#ifndef IPK_RB_CPT
+#define IPK_RB_CPT 2
+#endif
+
 template <uint32_t TBL, int NT, bool COMPRESS = false>
 __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restrict__ pool,
                                                            const uint64_t* __restrict__ off, const uint2* __restrict__ list,
@@ -924,34 +972,39 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint64_t c0 = off[gb], c1 = off[gb + 1];
     // first chunk descriptors are requested before the table is cleared
+    constexpr int CPT = IPK_RB_CPT;                         // chunks per wavefront and trip: all their pair loads are issued before the first LDS atomic
     uint64_t ci = c0 + wave;
-    uint2 e0 = make_uint2(0, 0), e1 = make_uint2(0, 0);
-    if (ci < c1) e0 = list[ci];
-    if (ci + NWV < c1) e1 = list[ci + NWV];
+    uint2 e[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) { e[c] = make_uint2(0, 0); if (ci + (uint64_t)c * NWV < c1) e[c] = list[ci + (uint64_t)c * NWV]; }
     constexpr uint32_t CLR = COMPRESS ? comp_padded_slots<TBL, NT>() : TBL;      // (the compress epilogue reads whole blocks per wavefront)
     for (uint32_t i = threadIdx.x; i < CLR / 4; i += NT) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t k0 = (uint32_t)key0;
     while (ci < c1) {
-        const uint2* s0 = pool + (size_t)e0.x * CH;
-        const uint2* s1 = pool + (size_t)e1.x * CH;
-        const uint32_t n0 = e0.y, n1 = (ci + NWV < c1) ? e1.y : 0u;
         constexpr int PER = CH / 64;                        // loads per lane and chunk
-        uint2 v[2 * PER];
+        uint2 v[CPT * PER];
+        uint32_t n[CPT];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            v[j] = make_uint2(0, 0); v[PER + j] = make_uint2(0, 0);
-            if (lane + 64 * j < n0) v[j] = s0[lane + 64 * j];
-            if (lane + 64 * j < n1) v[PER + j] = s1[lane + 64 * j];
-        }
-        ci += 2 * NWV;
-        if (ci < c1) e0 = list[ci];
-        if (ci + NWV < c1) e1 = list[ci + NWV];
+        for (int c = 0; c < CPT; ++c) {
+            n[c] = (ci + (uint64_t)c * NWV < c1) ? e[c].y : 0u;
+            const uint2* s = pool + (size_t)e[c].x * CH;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            if (lane + 64 * j < n0) atomicMax(&tab[v[j].x - k0], enc_score_bits(v[j].y));
-            if (lane + 64 * j < n1) atomicMax(&tab[v[PER + j].x - k0], enc_score_bits(v[PER + j].y));
+            for (int j = 0; j < PER; ++j) {
+                v[c * PER + j] = make_uint2(0, 0);
+                if constexpr (IPK_RB_ABL & 1) { if (lane + 64 * j < n[c]) v[c * PER + j] = make_uint2(k0 + ((lane * 97u + j * 13u + (uint32_t)ci) & (TBL - 1)), lane); }
+                else if (lane + 64 * j < n[c]) v[c * PER + j] = s[lane + 64 * j];
+            }
         }
+        ci += (uint64_t)CPT * NWV;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) if (ci + (uint64_t)c * NWV < c1) e[c] = list[ci + (uint64_t)c * NWV];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c)
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if constexpr (IPK_RB_ABL & 2) { if (v[c * PER + j].x == 0xFFFFFFFFu) tab[0] = v[c * PER + j].y; }
+                else if (lane + 64 * j < n[c]) atomicMax(&tab[v[c * PER + j].x - k0], enc_score_bits(v[c * PER + j].y));
     }
     __syncthreads();
     if constexpr (COMPRESS) {

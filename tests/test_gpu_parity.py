@@ -610,6 +610,32 @@ def test_workgroups_that_draw_their_tiles(k):
             eng.close()
 
 
+@pytest.mark.parametrize("k,n_groups,sites", [(12, 3, 300), (11, 2, 500), (12, 1, 40), (12, 7, 1500)])
+def test_persistent_reduce_of_128_kb_slices(k, n_groups, sites):
+    """DNA k = 11, 12: a (group, key bucket) slice is a 128-KB LDS table, one workgroup per CU.  reduce_buckets_pipe_kernel keeps
+    a workgroup on its CU and streams the slices' chunks through two register buffers (kernels_reduce_pipe.hpp); the
+    workgroup-per-slice kernel stays behind debug_flags bit 11.  Both against the oracle (branch_group.cpp:88-101, `put`), group-major
+    and key-major; more slices than CUs, workgroups with one slice and with several, empty slices (40 sites touch few buckets)."""
+    sigma = 4
+    mats = synth_matrices(2 * n_groups, sites, sigma, 0.07, 700 + k + n_groups)
+    groups = np.repeat(np.arange(n_groups, dtype=np.uint32) + 3, 2)
+    eps = co.log_threshold(1.5, sigma, k)
+    parts_out = []
+    for flags in (0, 2048):
+        eng = ipk_amd.Engine(0)
+        try:
+            eng.set_option("debug_flags", flags)
+            if sites <= 500:
+                check_against_oracle(eng, mats, groups, k, eps)
+            parts = eng.score_groups_keymajor(mats, groups, k, eps, n_owners=1)
+            parts_out.append((parts.emitted, parts.counts_tensor().cpu().numpy().copy(), parts.entries_tensor().cpu().numpy().copy()))
+            parts.free()
+        finally:
+            eng.close()
+    assert parts_out[0][0] == parts_out[1][0]
+    assert np.array_equal(parts_out[0][1], parts_out[1][1]) and np.array_equal(parts_out[0][2], parts_out[1][2])
+
+
 @pytest.mark.parametrize("n_groups,world", [(70, 1), (130, 3), (5, 2)])
 def test_dense_writer_with_line_aligned_stores(n_groups, world):
     """km_write_lines_kernel cuts every store at a 128-byte line of the output and carries the rest of a key's entries as a tail of
