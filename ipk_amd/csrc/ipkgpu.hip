@@ -922,6 +922,9 @@ uint32_t xp_bucket_slots(uint32_t sigma, uint32_t k)
 #undef M_XT
     return 0;
 }
+#ifndef IPK_KMC_RUNS_DEFAULT
+#define IPK_KMC_RUNS_DEFAULT 1
+#endif
 #define KM_LAUNCH(KERN, CAPV, ...)                                                                                        \
     do {                                                                                                                  \
         if (P == 1) hipLaunchKernelGGL((KERN<true, CAPV>), dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream, __VA_ARGS__); \
@@ -2167,8 +2170,16 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         // the key-major writer over `cap_e` entries of room
         auto launch_writer = [&](uint64_t cap_e) -> int {
             if (ctx->table_compressed) {
-                const uint64_t per_xcd = (((T + 63) / 64) + 7) / 8;
-                if (qpack)
+                uint64_t per_xcd = (((T + 63) / 64) + 7) / 8;
+                // (the writer that walks runs of consecutive key blocks; debug_flags bit 12: one workgroup per key block)
+                // Measured (r04): 8 % faster at a cfg3 share (125 groups: 32 rows per wavefront), 9 % SLOWER at cfg4 and cfg5's passes (250 /
+                // 256 groups: 64 rows per wavefront, where the writer already moves its bytes at 4.4 TB/s) -- so only up to 128 groups.
+                const bool runs = !(ctx->opt_flags & 4096) && IPK_KMC_RUNS_DEFAULT && (gb <= 128 || (ctx->opt_flags & 8192));
+                if (runs && (qpack || fast_c)) per_xcd = (kmc_runs(T, ctx->comp_tbl) + 7) / 8;
+                if (qpack && runs)
+                    KM_LAUNCH(km_write_c_run_kernel, KMC_CAP, comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots, b.counts,
+                              qpack, ctx->offsets.as<uint64_t>(), b.entries, cap_e);
+                else if (qpack)
                     KM_LAUNCH(km_write_c_kernel, KMC_CAP, comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots, b.counts,
                               qpack, ctx->offsets.as<uint64_t>(), b.entries, cap_e);
                 else if (fast_c) {
@@ -2189,12 +2200,16 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
                         ctp.mask = pmask;
                         ctp.vaddr += (size_t)p0 * (ctx->mask_words / 2);
                         ctp.rank += (size_t)p0 * (ctx->mask_words / 2);
-                        KM_LAUNCH(km_write_c_kernel, KMC_CAP, ctp, T, pg, ctx->branch.as<uint32_t>() + g0 + p0, P, slots, ctx->pcounts.as<uint32_t>(),
-                                  ctx->qpack.as<uint32_t>(), ctx->offsets.as<uint64_t>(), b.entries, cap_e);
+                        if (runs)
+                            KM_LAUNCH(km_write_c_run_kernel, KMC_CAP, ctp, T, pg, ctx->branch.as<uint32_t>() + g0 + p0, P, slots, ctx->pcounts.as<uint32_t>(),
+                                      ctx->qpack.as<uint32_t>(), ctx->offsets.as<uint64_t>(), b.entries, cap_e);
+                        else
+                            KM_LAUNCH(km_write_c_kernel, KMC_CAP, ctp, T, pg, ctx->branch.as<uint32_t>() + g0 + p0, P, slots, ctx->pcounts.as<uint32_t>(),
+                                      ctx->qpack.as<uint32_t>(), ctx->offsets.as<uint64_t>(), b.entries, cap_e);
                         HIP_TRY(ctx, hipGetLastError());
                     }
                 } else
-                    hipLaunchKernelGGL(km_write_c_generic_kernel, dim3((uint32_t)(per_xcd * 8)), dim3(256), 0, ctx->stream,
+                    hipLaunchKernelGGL(km_write_c_generic_kernel, dim3((uint32_t)((((T + 63) / 64 + 7) / 8) * 8)), dim3(256), 0, ctx->stream,
                                        comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots,
                                        ctx->offsets.as<uint64_t>(), b.entries, cap_e);
             } else if ((ctx->opt_flags & 512) || (gb < 96 && !(ctx->opt_flags & 1024)))

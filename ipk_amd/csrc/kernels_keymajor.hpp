@@ -611,7 +611,11 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
 #else
                             mmq[u] = *reinterpret_cast<const uint2*>(&rowmeta[wave][b8 + b4 + u]);
 #endif
+#if IPK_KMC_RL >= 2
+                            brq[u] = (uint32_t)__builtin_amdgcn_readlane((int)row_br, (int)(b8 + b4 + u));
+#else
                             brq[u] = rowbr[wave][b8 + b4 + u];
+#endif
                         }
 #pragma unroll
                         for (uint32_t u = 0; u < SB; ++u) {
@@ -672,6 +676,215 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
     }
     // the advanced cursors (batches of groups append in order)
     if (threadIdx.x < 64 && x < T) cursor[cidx] = kcur[threadIdx.x] + my_cnt;
+}
+
+// km_write_c_kernel walking a RUN of up to KMC_RUN consecutive key blocks of one bucket slice (round 4).
+//
+// After the rows' bits and addresses stopped going through LDS, the vector-memory path was what the writer waited for
+// (r04b_cfg4_backhalf_sq.json: the L1 "pending" 85 % of the time, address unit stalled by the cache 38 %, 909 64-byte read requests
+// per key block): more than half of those requests were the lane-per-row loads of a block's bits and value addresses -- 8 useful
+// bytes out of every line, 512 lines per workgroup.  Consecutive blocks of a row are consecutive in memory, and inside a bucket
+// slice the next block's values follow this block's (vaddr[g][blk + 1] = vaddr[g][blk] + 4 * popcount(bits[g][blk]),
+// compress_slice), so a workgroup that walks R consecutive blocks loads a row's bits for all of them at once (R x 8 contiguous
+// bytes per lane) and a row's value address ONCE: 2 / R requests per row and block instead of 2.  The blocks are done one after the
+// other with the stage, the key prefix and everything else of km_write_c_kernel; the next block's per-key counts and cursors are
+// requested while this block is copied out.
+#ifndef IPK_KMC_RUN
+#define IPK_KMC_RUN 4
+#endif
+#ifndef IPK_KMC_WPE
+#define IPK_KMC_WPE 1            // 1: registers bounded for four wavefronts per SIMD (four workgroups per CU, as km_write_c_kernel)
+#endif
+#if IPK_KMC_WPE
+#define KMC_RUN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define KMC_RUN_OCCUPANCY
+#endif
+constexpr uint32_t KMC_RUN = IPK_KMC_RUN;
+__host__ __device__ inline uint64_t kmc_runs(uint64_t T, uint32_t TBL)
+{
+    const uint64_t nblocks = (T + 63) / 64, bpb = TBL / 64, nbuckets = (nblocks + bpb - 1) / bpb;
+    return nbuckets * ((bpb + KMC_RUN - 1) / KMC_RUN);
+}
+template <bool ONE_OWNER, uint32_t CAP>
+__global__ __launch_bounds__(256) KMC_RUN_OCCUPANCY void km_write_c_run_kernel(CompTable ct, uint64_t T, uint32_t G,
+                                                             const uint32_t* __restrict__ branch_of_group, uint32_t P,
+                                                             uint64_t slots, const uint32_t* __restrict__ counts,
+                                                             const uint32_t* __restrict__ qpack,
+                                                             uint64_t* __restrict__ cursor, uint2* __restrict__ entries, uint64_t cap_entries)
+{
+    __shared__ uint2 out[CAP];
+    if (cursor[(uint64_t)P * slots] > cap_entries) return;       // (see km_write_kernel)
+    __shared__ uint32_t rowbr[4][64];                        // per wavefront and row: branch id
+    __shared__ uint32_t kpre[65];                            // exclusive prefix of the block's per-key entry counts
+    __shared__ uint64_t kcur[64];                            // the keys' output positions
+    const uint64_t nblocks = (T + 63) / 64, bpb = ct.TBL / 64, rpb = (bpb + KMC_RUN - 1) / KMC_RUN;
+    const uint64_t nruns = kmc_runs(T, ct.TBL), per_xcd = (nruns + 7) / 8;
+    const uint64_t run = (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);    // (each XCD walks a contiguous range of runs)
+    if ((blockIdx.x >> 3) >= per_xcd || run >= nruns) return;
+    const uint64_t bucket = run / rpb;
+    const uint64_t kb0 = bucket * bpb + (run - bucket * rpb) * KMC_RUN;
+    if (kb0 >= nblocks) return;
+    const uint32_t nb = (uint32_t)(min(min(kb0 + KMC_RUN, (bucket + 1) * bpb), nblocks) - kb0);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+
+    // this wavefront's rows [r0, r0 + nrows), nrows <= 64: lane = row.  The bits of all the run's blocks, the value address of the
+    // first block, the branch id.
+    const uint32_t rq = (G + 3) / 4, r0 = min(G, wave * rq), nrows = min(G, r0 + rq) - r0;
+    uint64_t mq[KMC_RUN];
+    uint64_t row_va = reinterpret_cast<uint64_t>(ct.pool);                                // (rows past the end: no bits, any readable address)
+    uint32_t row_br = 0;
+    {
+        const uint32_t row_bytes = (uint32_t)(ct.mask_words / 2) * 8u;                   // a row of bits / of addresses
+        const bool live = lane < nrows;
+        const size_t ro = (size_t)(r0 + (live ? lane : 0u)) * row_bytes;
+        const uint64_t* mrow = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(reinterpret_cast<const uint64_t*>(ct.mask) + kb0) + ro);
+#pragma unroll
+        for (uint32_t i = 0; i < KMC_RUN; ++i) mq[i] = (live && i < nb) ? mrow[i] : 0ull;
+        if (live) {
+            row_va = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(ct.vaddr + kb0) + ro);
+            row_br = branch_of_group[r0 + lane];
+        }
+    }
+    rowbr[wave][lane] = row_br;
+
+    // the first block's keys: where they live, how many rows of the quarters before this wavefront's hold them
+    auto key_index = [&](uint64_t x) -> size_t { return x < T ? (ONE_OWNER ? (size_t)x : (size_t)((x % P) * slots + x / P)) : 0; };
+    size_t cidx = key_index(kb0 * 64 + lane);
+    uint32_t qp = kb0 * 64 + lane < T ? qpack[cidx] : 0u;
+    uint32_t my_cnt = 0;
+    uint64_t cur = 0;
+    if (threadIdx.x < 64 && kb0 * 64 + lane < T) { my_cnt = counts[cidx]; cur = cursor[cidx]; }
+    const uint32_t out_lds = lds_address(out);
+
+    for (uint32_t it = 0; it < nb; ++it) {
+        const uint64_t x = (kb0 + it) * 64 + lane;
+        const uint64_t row_m = mq[0];
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 3; ++w) before += w < wave ? (qp >> (8u * w)) & 0xFFu : 0u;
+        if (threadIdx.x < 64) {
+            kcur[threadIdx.x] = cur;
+            uint32_t inc = my_cnt;
+            for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+            kpre[threadIdx.x + 1] = inc;
+            if (threadIdx.x == 0) kpre[0] = 0;
+        }
+        const uint32_t cnt_now = my_cnt;
+
+        // the value loads of all rows, none waited for here.  Every lane loads: a lane without the key reads the value of the next
+        // key that has one (or, past the row's end, whatever follows it in the pool, which is allocated 256 B longer for this) and
+        // does not store it.
+        uint32_t val[64];
+        const uint32_t rm_lo = (uint32_t)row_m, rm_hi = (uint32_t)(row_m >> 32), ra_lo = (uint32_t)row_va, ra_hi = (uint32_t)(row_va >> 32);
+#pragma unroll
+        for (uint32_t b8 = 0; b8 < 64; b8 += 8) {
+            if (b8 < nrows) {
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t r = b8 + u;
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)rm_lo, (int)r), mhi = (uint32_t)__builtin_amdgcn_readlane((int)rm_hi, (int)r);
+                    const uint32_t alo = (uint32_t)__builtin_amdgcn_readlane((int)ra_lo, (int)r), ahi = (uint32_t)__builtin_amdgcn_readlane((int)ra_hi, (int)r);
+                    const uint32_t j = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                    const global_u32_ptr vals = (global_u32_ptr)(((uint64_t)ahi << 32) | alo);
+                    val[r] = __builtin_nontemporal_load(vals + j);
+                }
+            }
+        }
+        // the next block of the run: its values follow this block's; its bits move up; its keys' counts and cursors are requested now
+        row_va += 4ull * (uint32_t)__popcll(row_m);
+#pragma unroll
+        for (uint32_t i = 0; i + 1 < KMC_RUN; ++i) mq[i] = mq[i + 1];
+        mq[KMC_RUN - 1] = 0;
+        if (it + 1 < nb) {
+            const uint64_t xn = x + 64;
+            cidx = key_index(xn);
+            qp = xn < T ? qpack[cidx] : 0u;
+            my_cnt = 0; cur = 0;
+            if (threadIdx.x < 64 && xn < T) { my_cnt = counts[cidx]; cur = cursor[cidx]; }
+        }
+        __syncthreads();
+
+        for (uint32_t ka = 0; ka < 64;) {
+            // the key range [ka, ke) of this round: as many keys as fit the stage
+            const uint32_t pre_a = kpre[ka];
+            const uint32_t fits = (uint32_t)__popcll(ballot64(lane >= ka && kpre[lane + 1] - pre_a <= CAP));
+            const uint32_t ke = ka + max(fits, 1u);                                         // (G <= CAP: one key always fits)
+            const uint32_t n_part = kpre[ke] - pre_a;
+            if (n_part == 0) { ka = ke; continue; }
+            const uint64_t pm = (ke >= 64 ? ~0ull : ((1ull << ke) - 1ull)) & ~((1ull << ka) - 1ull);
+            const uint32_t pm_lo = (uint32_t)pm, pm_hi = (uint32_t)(pm >> 32);
+
+            // the rows' entries into the stage  (lanes outside the range never store; a whole block needs no masking)
+            uint32_t posb = out_lds + (kpre[lane] - pre_a + before) * 8u;
+            auto scatter = [&](auto WHOLE, uint32_t& pb) {                                  // (pb: an asm operand must not be a capture)
+                constexpr uint32_t SB = IPK_KMC_SB;                                          // rows whose branch ids are read together
+#pragma unroll
+                for (uint32_t b8 = 0; b8 < 64; b8 += 8) {
+                    if (b8 < nrows) {
+#pragma unroll
+                        for (uint32_t b4 = 0; b4 < 8; b4 += SB) {
+                            uint2 mmq[SB]; uint32_t brq[SB];
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (uint32_t u = 0; u < SB; ++u) {
+                                mmq[u] = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rm_lo, (int)(b8 + b4 + u)),
+                                                    (uint32_t)__builtin_amdgcn_readlane((int)rm_hi, (int)(b8 + b4 + u)));
+                                brq[u] = rowbr[wave][b8 + b4 + u];
+                            }
+#pragma unroll
+                            for (uint32_t u = 0; u < SB; ++u) {
+                                uint2 mm = mmq[u];
+                                if constexpr (!decltype(WHOLE)::value) { mm.x &= pm_lo; mm.y &= pm_hi; }
+                                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.x);
+                                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)mm.y);
+                                IPK_ASSERT_FULL_EXEC();
+                                const uint32_t ex = brq[u], ey = val[b8 + b4 + u];          // (locals: an asm operand must not be a capture)
+                                asm volatile("s_mov_b64 exec, %3\n\tds_write2_b32 %0, %1, %2 offset1:1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, -1"
+                                             : "+v"(pb) : "v"(ex), "v"(ey), "s"(((uint64_t)hi << 32) | lo) : "memory");
+                            }
+                        }
+                    }
+                }
+            };
+            if (pm == ~0ull) scatter(std::true_type{}, posb); else scatter(std::false_type{}, posb);
+            // (the scatter's writes live inside asm statements the compiler's wait-count pass does not see: see km_write_c_kernel)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            // copy out
+            bool linear = ONE_OWNER;
+            if (ONE_OWNER) {                                     // (a fresh scan makes consecutive keys adjacent; checked, not assumed)
+                const bool ok = lane < ka || lane + 1 >= ke || kcur[lane] + (kpre[lane + 1] - kpre[lane]) == kcur[lane + 1];
+                linear = ballot64(ok) == ~0ull;
+            }
+            if (linear) {
+                uint2* dst = entries + kcur[ka];
+#pragma unroll 2
+                for (uint32_t i = threadIdx.x; i < n_part; i += 256) {
+                    uint2 e = out[i];
+                    e.y = dec_score_bits_bf(e.y);
+                    dst[i] = e;
+                }
+            } else {
+                for (uint32_t t = ka + wave; t < ke; t += 4) {
+                    const uint32_t n = kpre[t + 1] - kpre[t];
+                    const uint2* src = out + (kpre[t] - pre_a);
+                    uint2* dst = entries + kcur[t];
+                    for (uint32_t i = lane; i < n; i += 64) {
+                        uint2 e = src[i];
+                        e.y = dec_score_bits_bf(e.y);
+                        dst[i] = e;
+                    }
+                }
+            }
+            ka = ke;
+            if (ka < 64) __syncthreads();                        // the stage is reused
+        }
+        // the advanced cursors (batches of groups append in order)
+        if (threadIdx.x < 64 && x < T) cursor[key_index(x)] = kcur[threadIdx.x] + cnt_now;
+        __syncthreads();                                         // stage, key prefix and cursors are the next block's now
+    }
 }
 
 // ---- merge of S sources for one owner -----------------------------------------------------------

@@ -343,6 +343,8 @@ struct StreamParams {
                                    // (host) bit 6 = every wait of the call as in round 2 (no device-side counts, no estimated allocations),
                                    // (host) bit 7 = fixed tile ranges, bit 8 = drawn tiles whatever the tile count (tests),
                                    // (host) bit 9 = dense key-major writer with tile-by-tile stores, bit 10 = with line-cut stores, whatever the group count
+                                   // (host) bit 11 = 128-KB slices reduced by the workgroup-per-slice kernel instead of the persistent one,
+                                   // (host) bit 12 = compressed key-major writer per key block, bit 13 = per run of blocks whatever the group count
     uint32_t pre_chunks;           // row-per-lane quad kernel: chunks [0, pre_chunks) are handed out by position -- wavefront w's bucket b
                                    // starts in chunk w * NB + b -- and pool_next starts at pre_chunks (0: every first chunk is drawn)
     uint32_t* tile_next = nullptr; // quad kernel: [groups] next tile of each group -- its S workgroups DRAW their tiles instead of

@@ -290,6 +290,34 @@ def test_mif0_order_matches_the_sequential_oracle(engine):
     db.free(); parts.free()
 
 
+@pytest.mark.parametrize("sigma,k,n_groups,sites,world", [(4, 12, 6, 400, 1), (4, 12, 3, 150, 3), (20, 6, 5, 60, 1), (20, 6, 4, 40, 2),
+                                                          (4, 11, 140, 40, 1)])
+def test_compressed_writer_per_block_and_per_run(sigma, k, n_groups, sites, world):
+    """The key-major writer on compressed tables, two forms: one workgroup per 64-key block (km_write_c_kernel, debug_flags bit 12)
+    and one per run of consecutive blocks of a bucket slice (km_write_c_run_kernel: a row's bits for the whole run in one load, its
+    value address once, the next block's by counting bits; default up to 128 groups, bit 13 forces it beyond).  Same parts, equal to
+    the oracle's database (db_builder.cpp:685-694: entries of a k-mer in group order)."""
+    import ipk_amd
+    mats = synth_matrices(n_groups, sites, sigma, 0.08 if sigma == 4 else 0.03, 77 + n_groups + k)
+    groups = np.arange(n_groups, dtype=np.uint32) + 4
+    eps = co.log_threshold(1.5, sigma, k)
+    out = []
+    for flags in (4096, 8192):
+        eng = ipk_amd.Engine(0)
+        try:
+            eng.set_option("debug_flags", flags)
+            parts = eng.score_groups_keymajor(mats, groups, k, eps, n_owners=world)
+            out.append((parts.emitted, parts.counts_tensor().cpu().numpy().copy(), parts.entries_tensor().cpu().numpy().copy(), list(parts.owner_offsets)))
+            parts.free()
+        finally:
+            eng.close()
+    assert out[0][0] == out[1][0] and out[0][3] == out[1][3]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    if sites <= 60:
+        full = dbo.build_db([(int(groups[g]),) + co.explore_group(mats[g:g + 1], k, eps)[:2] for g in range(n_groups)])
+        assert int(out[0][1].sum()) == sum(len(v) for v in full.values())
+
+
 @pytest.mark.parametrize("protocol", [None, "0"])
 def test_device_writer_and_host_writer_write_the_same_bytes(engine, tmp_path, monkeypatch, protocol):
     """ipkgpu_db_write (records packed on the device, streamed) against ipkgpu_db_write_host over the same shard, with and
