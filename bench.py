@@ -381,6 +381,9 @@ def main():
                        "sharding": f"branch groups over {world} rank(s)" + ("; k-mer-keyed all-to-all (RCCL) + merge" if world > 1 and args.output == "db" else "; no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         # (not measured in this run: PMC counters need their own rocprofv3 passes -- the figure is the committed capture)
+                         "traffic_source": (os.path.relpath(tfile, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_traffic.sh, "
+                                            "not collected in this run)") if traffic is not None else None,
                          "kernel": main_kernel, "avg_launch_ms": avg_main_ms, "kernels": kernels,
                          "algorithmic_bytes_per_launch": b_alg,
                          "score_phase_ms": avg_score_ms, "score_phase_GBps": b_alg / (avg_score_ms * 1e-3) / 1e9 if avg_score_ms > 0 else 0.0},
@@ -392,6 +395,11 @@ def main():
                                    "per_rank_device_total": rank_ms},
             "setup_s": {"synth_and_upload": t_gen, "engine_init_first_call": t_init},
         }
+        if world > 1 and args.output == "db":
+            # the piece rule's arithmetic beside what was measured (pieces used: n_pieces): per-group cost from this run's device time
+            per_group = max(0.0, (total_ms / args.steps - (n_pieces or 1) * 0.52) / max(ng, 1))
+            out["pieces_used"] = n_pieces or 1
+            out["pieces_model"] = D.pieces_model(ng, world, entries, per_group)
         if world == 1 and args.e2e:
             import subprocess
             try:

@@ -62,6 +62,28 @@ def default_pieces(n_groups):
     return int(min(4, max(1, n_groups // 48)))
 
 
+def pieces_model(n_groups, world, entries_per_rank, ms_per_group, call_ms=0.52, link_gb_s=100.0, merge_ms=0.5, max_pieces=3):
+    """What cutting a rank's share into p pieces should cost, per step (ms) -- arithmetic on one-GPU measurements, printed into the
+    N > 1 bench line so that the first run on a multi-GPU node can be read against it.
+
+    A piece is a scoring call (call_ms before its first group: the intercept of tools/sweep_groups.sh, + ms_per_group each) followed
+    by its k-mer-keyed all-to-all, which runs under the NEXT piece's scoring; the last piece's transfer is exposed in full, an earlier
+    one only by what outlasts the scoring it hides behind.  A rank sends (world - 1) / world of its entries (8 bytes each) over
+    world - 1 direct links at once (link_gb_s each: an ASSUMPTION until measured; xGMI's 153 GB/s is the link's peak)."""
+    out = []
+    score_all = n_groups * ms_per_group
+    send_bytes = 8.0 * entries_per_rank * (world - 1) / max(world, 1)
+    xfer_all = send_bytes / max(world - 1, 1) / (link_gb_s * 1e9) * 1e3 if world > 1 else 0.0
+    for p in range(1, max_pieces + 1):
+        score = p * call_ms + score_all
+        xfer = xfer_all / p
+        exposed = xfer + (p - 1) * max(0.0, xfer - (score_all / p + call_ms))
+        out.append({"pieces": p, "scoring_ms": score, "extra_fixed_ms": (p - 1) * call_ms, "exchange_exposed_ms": exposed,
+                    "merge_ms": merge_ms if world > 1 else 0.0, "step_ms": score + exposed + (merge_ms if world > 1 else 0.0)})
+    return {"assumptions": {"call_ms": call_ms, "ms_per_group": ms_per_group, "link_GB_s": link_gb_s, "merge_ms": merge_ms,
+                            "entries_per_rank": entries_per_rank, "groups_per_rank": n_groups, "world": world}, "by_pieces": out}
+
+
 def exchange_parts(counts, entries, owner_offsets, dist, world):
     """Rehearsal transport (torch.distributed): all-to-all of the per-owner blocks of ONE piece.
 

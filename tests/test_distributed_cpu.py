@@ -110,3 +110,19 @@ def test_ranks_agree_on_the_piece_count(tmp_path):
 def test_default_pieces_follow_the_share_size():
     from ipk_amd import distributed as D
     assert [D.default_pieces(n) for n in (0, 1, 47, 48, 125, 250, 1000)] == [1, 1, 1, 1, 2, 4, 4]
+
+
+def test_pieces_model_arithmetic():
+    """The piece rule's model (printed into the N > 1 bench line): more pieces cost their fixed call time and hide all but the last
+    piece's transfer while a piece's scoring outlasts it; one rank has nothing to exchange."""
+    from ipk_amd import distributed as D
+    m = D.pieces_model(125, 8, 118_000_000, 0.0197)
+    by = {r["pieces"]: r for r in m["by_pieces"]}
+    assert abs(by[1]["scoring_ms"] - (0.52 + 125 * 0.0197)) < 1e-9 and by[2]["extra_fixed_ms"] == 0.52
+    full = 8.0 * 118_000_000 * 7 / 8 / 7 / 100e9 * 1e3                     # one link's share of the rank's entries, ms
+    assert abs(by[1]["exchange_exposed_ms"] - full) < 1e-9 and abs(by[2]["exchange_exposed_ms"] - full / 2) < 1e-9
+    assert by[3]["step_ms"] > by[3]["scoring_ms"]
+    slow = D.pieces_model(4, 8, 118_000_000, 0.0197, link_gb_s=1.0)         # a transfer far longer than a piece's scoring stays exposed
+    assert slow["by_pieces"][1]["exchange_exposed_ms"] > slow["by_pieces"][0]["exchange_exposed_ms"] * 0.9
+    one = D.pieces_model(1000, 1, 10 ** 9, 0.0186)
+    assert all(r["exchange_exposed_ms"] == 0.0 and r["merge_ms"] == 0.0 for r in one["by_pieces"])

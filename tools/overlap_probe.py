@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--groups", type=int, default=0)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--offset-ms", type=float, default=0.0, help="start the second thread this much later")
+    ap.add_argument("--phase", default="all", choices=["all", "seq", "par"], help="time only this phase (for a kernel trace of it)")
     a = ap.parse_args()
     cfg = dict(CONFIGS[a.config])
     ng = a.groups or cfg["n_groups"]
@@ -56,14 +57,20 @@ def main():
     for _ in range(2):
         one(0); one(1); whole_step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        whole_step()
-    t_whole = (time.perf_counter() - t0) / a.steps
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one(0); one(1)
-    t_seq = (time.perf_counter() - t0) / a.steps
+    t_whole = t_seq = float("nan")
+    if a.phase == "all":
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            whole_step()
+        t_whole = (time.perf_counter() - t0) / a.steps
+    if a.phase in ("all", "seq"):
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            one(0); one(1)
+        t_seq = (time.perf_counter() - t0) / a.steps
+    if a.phase == "seq":
+        print(f"{a.config} {2 * half} groups: halves one after the other {t_seq * 1e3:.2f} ms")
+        return
 
     def worker(i, delay):
         if delay:
