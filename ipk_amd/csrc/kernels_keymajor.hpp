@@ -482,7 +482,9 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
 {
     __shared__ uint2 out[CAP];
     if (cursor[(uint64_t)P * slots] > cap_entries) return;       // (see km_write_kernel)
+#if !IPK_KMC_RL
     __shared__ uint4 rowmeta[4][64];                         // per wavefront and row: occupancy bits, address of the values
+#endif
     __shared__ uint32_t rowbr[4][64];                        //                        branch id
     __shared__ uint32_t kpre[65];                            // exclusive prefix of the block's per-key entry counts
     __shared__ uint64_t kcur[64];                            // the keys' output positions
@@ -529,7 +531,9 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
         if (threadIdx.x == 0) kpre[0] = 0;
     }
 
+#if !IPK_KMC_RL
     rowmeta[wave][lane] = make_uint4((uint32_t)row_m, (uint32_t)(row_m >> 32), (uint32_t)row_va, (uint32_t)(row_va >> 32));
+#endif
     rowbr[wave][lane] = row_br;
     // the value loads of all rows, none waited for here.  Every lane loads: a lane without the key reads the value of the next
     // key that has one (or, past the row's end, whatever follows it in the pool, which is allocated 256 B longer for this) and

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NT) void reduce_buckets_pipe_kernel(const uint2* __
 #pragma unroll
             for (int q = 0; q < PER; ++q) {                  // (the select is wave-uniform: a scalar base per load, one lane offset for all)
                 const uint2* sq = s + ((uint32_t)(64 * q) < cnt ? 64u * q : 0u);
-                P[j * PER + q] = sq[lane];
+                P[j * PER + q] = pool_load(sq + lane);
             }
         }
         // the cursor moves on; the next trip's descriptors are requested

@@ -953,6 +953,18 @@ __device__ __forceinline__ void compress_slice(uint32_t* tab, uint32_t nslots, u
 #ifndef IPK_RB_CPT
 #define IPK_RB_CPT 2
 #endif
+#ifndef IPK_RB_NT
+#define IPK_RB_NT 0              // 1: the reduce kernels read the pair pool with non-temporal loads (read once, never again)
+#endif
+__device__ __forceinline__ uint2 pool_load(const uint2* p)
+{
+#if IPK_RB_NT
+    const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(p));
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+#else
+    return *p;
+#endif
+}
 
 template <uint32_t TBL, int NT, bool COMPRESS = false>
 __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restrict__ pool,
@@ -995,7 +1007,7 @@ __global__ __launch_bounds__(NT) void reduce_buckets_kernel(const uint2* __restr
             for (int j = 0; j < PER; ++j) {
                 v[c * PER + j] = make_uint2(0, 0);
                 if constexpr (IPK_RB_ABL & 1) { if (lane + 64 * j < n[c]) v[c * PER + j] = make_uint2(k0 + ((lane * 97u + j * 13u + (uint32_t)ci) & (TBL - 1)), lane); }
-                else if (lane + 64 * j < n[c]) v[c * PER + j] = s[lane + 64 * j];
+                else if (lane + 64 * j < n[c]) v[c * PER + j] = pool_load(s + lane + 64 * j);
             }
         }
         ci += (uint64_t)CPT * NWV;
@@ -1471,7 +1483,7 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(uint2* __restrict__ p
     uint2 v[PER];
     uint64_t i = r0 + threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) if (i + (uint64_t)j * NT < r1) v[j] = pool[i + (uint64_t)j * NT];   // in flight while the table is cleared
+    for (int j = 0; j < PER; ++j) if (i + (uint64_t)j * NT < r1) v[j] = pool_load(pool + i + (uint64_t)j * NT);   // in flight while the table is cleared
     constexpr uint32_t CLR = COMPRESS ? comp_padded_slots<TBL, NT>() : TBL;      // (the compress epilogue reads whole blocks per wavefront)
     for (uint32_t z = threadIdx.x; z < CLR / 4; z += NT) reinterpret_cast<uint4*>(tab)[z] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -1483,7 +1495,7 @@ __global__ __launch_bounds__(NT) void reduce_ranges_kernel(uint2* __restrict__ p
         const uint64_t ci = i;
         i += (uint64_t)PER * NT;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) if (i + (uint64_t)j * NT < r1) v[j] = pool[i + (uint64_t)j * NT];
+        for (int j = 0; j < PER; ++j) if (i + (uint64_t)j * NT < r1) v[j] = pool_load(pool + i + (uint64_t)j * NT);
 #pragma unroll
         for (int j = 0; j < PER; ++j)
             if (ci + (uint64_t)j * NT < r1) atomicMax(&tab[cur[j].x - k0], enc_score_bits(cur[j].y));
