@@ -102,6 +102,7 @@ struct ipkgpu_ctx {
     int64_t workspace_bytes = 0;
     int64_t opt_variant = 0;
     int64_t opt_flags = 0;
+    int64_t opt_kmc_pass = 0;            // groups per pass of the compressed key-major writer (0: IPK_KMC_PASS)
     int64_t opt_wg_chunks2 = 0;       // tuning knob: overrides IPK_WG_CHUNKS2 (0 = built-in), opt_rounds: IPK_ROUNDS
     int64_t opt_rounds = 0;
     int64_t opt_pool_limit = 0;       // test knob: bytes the pair pool may take (0 = what the device has free)
@@ -413,6 +414,7 @@ int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "debug_pool_limit_bytes")) { ctx->opt_pool_limit = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_wg_chunks2")) { ctx->opt_wg_chunks2 = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_rounds")) { ctx->opt_rounds = value; return IPKGPU_OK; }
+    if (!strcmp(name, "debug_kmc_pass")) { ctx->opt_kmc_pass = value; return IPKGPU_OK; }
     return fail(ctx, IPKGPU_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -924,6 +926,9 @@ uint32_t xp_bucket_slots(uint32_t sigma, uint32_t k)
 }
 #ifndef IPK_KMC_RUNS_DEFAULT
 #define IPK_KMC_RUNS_DEFAULT 1
+#endif
+#ifndef IPK_KMC_PASS
+#define IPK_KMC_PASS 256          // groups per pass of the compressed key-major writer (a batch of more groups takes several passes)
 #endif
 #define KM_LAUNCH(KERN, CAPV, ...)                                                                                        \
     do {                                                                                                                  \
@@ -2112,11 +2117,12 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
         HIP_TRY(ctx, ctx_alloc(ctx, (void**)&b.counts, n_slots_all * 4));
         HIP_TRY(ctx, hipMemsetAsync(b.counts, 0, n_slots_all * 4, ctx->stream));
         // compressed tables go through the fast key-major writer, up to 256 groups at a time: it wants those rows counted per quarter
+        const uint32_t kmc_pass = (uint32_t)std::min<int64_t>(256, std::max<int64_t>(4, ctx->opt_kmc_pass > 0 ? ctx->opt_kmc_pass : IPK_KMC_PASS));
         const bool fast_c = ctx->table_compressed && 64ull * (ctx->mask_words / 2) * 8 < (1ull << 32);
         uint32_t* qpack = nullptr;
         if (fast_c) {
             RC_TRY(ensure(ctx, ctx->qpack, n_slots_all * 4));
-            if (gb <= 256) qpack = ctx->qpack.as<uint32_t>();          // one pass: the total counts are the pass' counts
+            if (gb <= kmc_pass) qpack = ctx->qpack.as<uint32_t>();     // one pass: the total counts are the pass' counts
         }
         if (ctx->mask_valid && (T + 31) / 32 >= (uint64_t)ctx->num_cu * 1024)      // a thread per mask word fills the chip
             hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)(((T + 31) / 32 + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -2174,7 +2180,8 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
                 // (the writer that walks runs of consecutive key blocks; debug_flags bit 12: one workgroup per key block)
                 // Measured (r04): 8 % faster at a cfg3 share (125 groups: 32 rows per wavefront), 9 % SLOWER at cfg4 and cfg5's passes (250 /
                 // 256 groups: 64 rows per wavefront, where the writer already moves its bytes at 4.4 TB/s) -- so only up to 128 groups.
-                const bool runs = !(ctx->opt_flags & 4096) && IPK_KMC_RUNS_DEFAULT && (gb <= 128 || (ctx->opt_flags & 8192));
+                const uint32_t rows_now = qpack ? gb : std::min<uint32_t>(gb, kmc_pass);
+                const bool runs = !(ctx->opt_flags & 4096) && IPK_KMC_RUNS_DEFAULT && (rows_now <= 128 || (ctx->opt_flags & 8192));
                 if (runs && (qpack || fast_c)) per_xcd = (kmc_runs(T, ctx->comp_tbl) + 7) / 8;
                 if (qpack && runs)
                     KM_LAUNCH(km_write_c_run_kernel, KMC_CAP, comp_table(ctx), T, gb, ctx->branch.as<uint32_t>() + g0, P, slots, b.counts,
@@ -2186,8 +2193,8 @@ int ipkgpu_score_groups_keymajor_device(ipkgpu_ctx* ctx, const float* logp_dev, 
                     // more than 256 groups: passes of 256, each with its own counts; the cursors (the scan of the TOTAL counts) advance
                     // from pass to pass, so a key's entries stay in group order
                     RC_TRY(ensure(ctx, ctx->pcounts, n_slots_all * 4));
-                    for (uint32_t p0 = 0; p0 < gb; p0 += 256) {
-                        const uint32_t pg = std::min<uint32_t>(256, gb - p0);
+                    for (uint32_t p0 = 0; p0 < gb; p0 += kmc_pass) {
+                        const uint32_t pg = std::min<uint32_t>(kmc_pass, gb - p0);
                         const uint32_t* pmask = ctx->mask.as<uint32_t>() + (size_t)p0 * ctx->mask_words;
                         if ((T + 31) / 32 >= (uint64_t)ctx->num_cu * 1024)
                             hipLaunchKernelGGL(km_count_mask_kernel, dim3((uint32_t)(((T + 31) / 32 + 255) / 256)), dim3(256), 0, ctx->stream,
