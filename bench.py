@@ -286,6 +286,17 @@ def main():
     t0 = time.time()
     step(False)
     t_init = time.time() - t0
+    if n_pieces is not None and not os.environ.get("IPK_DIST_PIECES"):
+        # The piece rule knows group counts, not times (one piece per ~48 groups).  A second, timed step of this very workload says
+        # what a rank's scoring costs: one piece per ~3 ms of it, at most four -- pieces_model's optimum for a transfer of about the
+        # scoring's length (cfg3: 12.7 ms per rank -> 4 pieces; cfg2: 2.9 ms -> 1).  The smallest wish of all ranks wins, as before.
+        acc_probe = dict(acc)
+        step(True)
+        mine = (acc["total"] - acc_probe["total"]) - (n_pieces or 1) * 0.52
+        for kk in acc:
+            acc[kk] = acc_probe[kk]
+        want = int(min(4, max(1, round(mine / 3.0))))
+        n_pieces = D.agree_on_pieces(groups, want, dist, "cpu" if dist.get_backend() == "gloo" else "cuda")
     for _ in range(args.warmup):
         step(False)
     barrier()
