@@ -79,6 +79,75 @@ def cold_end_to_end(cfg, n_groups, device):
     return res
 
 
+def multi_rank_file_stages(eng, D, dist, d_logp, groups, k, eps, sigma, cfg, world, rank, n_pieces, ng_total):
+    """One more build on every rank, then the stages behind it, each bracketed by barriers (max over ranks = wall time): MIF0 on the
+    rank's shard, the shard written as a file (records packed on the device), rank 0's streaming merge of the P shard files.  Local
+    failures (no room for the files ...) are agreed on with an all-reduce before anything collective depends on them.  Skipped where
+    the files would not fit the scratch directory."""
+    import shutil
+    import tempfile
+    import torch
+    import ipk_amd
+    from ipk_amd import dbfile
+    cdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+
+    def wall(t0):
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    res = {}
+    dist.barrier(); t0 = time.perf_counter()
+    db, t = D.build_db_shard(eng, d_logp, groups, k, eps, sigma, dist, world, rank, pieces=n_pieces, agreed=n_pieces is not None)
+    res["build_s"] = wall(t0)
+    t0 = time.perf_counter()
+    db.filter_mif0(eng, ng_total + 1, ipk_amd.score_threshold(cfg["omega"], sigma, k))
+    res["filter_s"] = wall(t0)
+    tot = torch.tensor([db.num_keys, db.num_entries], dtype=torch.int64, device=cdev)
+    dist.all_reduce(tot)
+    file_bytes = int(tot[0].item()) * 16 + int(tot[1].item()) * 8
+    # one scratch directory for all ranks (they share the node): rank 0 makes it
+    name = [tempfile.mkdtemp(prefix="ipk_e2e_multi_") if rank == 0 else None]
+    dist.broadcast_object_list(name, 0)
+    tmpdir = name[0]
+    ok = 1
+    try:
+        free = shutil.disk_usage(tmpdir).free
+        if 2.2 * file_bytes > free:
+            ok = 0
+            res["skipped"] = f"shards + merged file need {2.2 * file_bytes / 1e9:.0f} GB, {free / 1e9:.0f} GB free in {tmpdir}"
+    except Exception as exc:
+        ok = 0; res["error"] = repr(exc)
+    okt = torch.tensor([ok], dtype=torch.int64, device=cdev); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    if int(okt.item()) == 1:
+        mine = os.path.join(tmpdir, f"shard{rank}.ipk")
+        dist.barrier(); t0 = time.perf_counter()
+        try:
+            dbfile.write_db_device(eng, db, mine, "DNA" if sigma == 4 else "AA", [], "", k, cfg["omega"])
+        except Exception as exc:
+            ok = 0; res["error"] = repr(exc)
+        res["shard_files_s"] = wall(t0)
+        okt = torch.tensor([ok], dtype=torch.int64, device=cdev); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 1:
+            dist.barrier(); t0 = time.perf_counter()
+            if rank == 0:
+                try:
+                    nk, ne = dbfile.merge_shard_files(os.path.join(tmpdir, "DB.ipk"), "DNA" if sigma == 4 else "AA", [], "", k, cfg["omega"],
+                                                      [os.path.join(tmpdir, f"shard{r}.ipk") for r in range(world)])
+                    res["kmers"], res["entries"] = nk, ne
+                    res["file_bytes"] = os.path.getsize(os.path.join(tmpdir, "DB.ipk"))
+                except Exception as exc:
+                    res["error"] = repr(exc)
+            res["merge_rank0_s"] = wall(t0)
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    db.free(); t.free()
+    res["note"] = "after the timed steps (workspaces warm): one build, then filter / shard files / rank 0's merge; wall = max over ranks"
+    return res if rank == 0 else None
+
+
 def launch_ranks(n, argv):
     """`python3 bench.py --gpus N` without a launcher: this process touches no GPU and starts the N ranks itself -- as a CHILD
     (`python -m torch.distributed.run`, rendezvous on 127.0.0.1), never by exec -- relays their output (rank 0's JSON line) and
@@ -327,6 +396,12 @@ def main():
         emitted_all = emitted
         n_ranks_seen = 1
 
+    # Several ranks, after the timed region: what the rest of a build costs on top of a step -- filter values on every rank's shard,
+    # the shards written as files, rank 0's merge of the shard files (merge_stage2's role, db_builder.cpp:392-458).  Warm, not cold.
+    e2e_multi = None
+    if world > 1 and args.output == "db" and args.e2e:
+        e2e_multi = multi_rank_file_stages(eng, D, dist, d_logp, groups, k, eps, sigma, cfg, world, rank, n_pieces, ng_total)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = emitted_all * args.steps / elapsed
@@ -409,6 +484,8 @@ def main():
         if world > 1 and args.output == "db":
             # the piece rule's arithmetic beside what was measured (pieces used: n_pieces): per-group cost from this run's device time
             per_group = max(0.0, (total_ms / args.steps - (n_pieces or 1) * 0.52) / max(ng, 1))
+            if e2e_multi is not None:
+                out["e2e_multi"] = e2e_multi
             out["pieces_used"] = n_pieces or 1
             out["pieces_model"] = D.pieces_model(ng, world, entries, per_group)
         if world == 1 and args.e2e:

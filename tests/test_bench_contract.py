@@ -84,6 +84,11 @@ def test_bench_two_ranks_on_one_gpu_self_launched():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["exchange"] == "torch" and d["value"] > 0
     assert d["scaling"] == "strong" and "roofline" in d
+    # the stages behind a step, timed after it: filter, shard files, rank 0's merge -- and the piece rule's arithmetic
+    em = d["e2e_multi"]
+    assert "error" not in em and em["kmers"] > 0 and em["entries"] > 0 and em["file_bytes"] > 16 * em["kmers"] + 8 * em["entries"]
+    assert all(em[x] >= 0 for x in ("build_s", "filter_s", "shard_files_s", "merge_rank0_s"))
+    assert d["pieces_used"] >= 1 and len(d["pieces_model"]["by_pieces"]) == 3
     # strong scaling: the two ranks together scored what one rank scores alone
     one = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--groups", "12", "--cpu-groups", "0", "--e2e", "0"], timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
