@@ -95,7 +95,10 @@ int64_t ipkgpu_debug_exec_violations(ipkgpu_ctx* ctx);
  * the compressed / the dense table form behind the chunked pool); "debug_flags" (bits 0-4: timing experiments inside the scoring
  * kernels, results wrong; 5: no first chunks by position; 6: every host wait of a call kept -- no device-side counts, no
  * allocations from estimates, no key list inside the scoring call; 7 / 8: the quad kernel's workgroups never / always draw
- * their tiles), "debug_pool_chunks", "debug_pool_limit_bytes", "debug_wg_chunks2", "debug_rounds" (diagnostics and tests only).
+ * their tiles; 9 / 10: the dense key-major writer with tile-by-tile / with line-cut stores whatever the group count; 11: 128-KB
+ * table slices reduced by the workgroup-per-slice kernel instead of the persistent one; 12 / 13: the compressed key-major writer
+ * per key block / per run of key blocks whatever the group count), "debug_pool_chunks", "debug_pool_limit_bytes",
+ * "debug_wg_chunks2", "debug_rounds", "debug_kmc_pass" (groups per pass of the compressed key-major writer) (diagnostics and tests only).
  * Every variant yields identical results.  Returns IPKGPU_ERR_INVALID for unknown names.
  *
  * Calls on one context are synchronous, but from its second scoring call on a context waits on its stream ONCE per key-major
