@@ -697,9 +697,10 @@ __global__ __launch_bounds__(256) void km_write_c_kernel(CompTable ct, uint64_t 
 #define IPK_KMC_RUN 4
 #endif
 #ifndef IPK_KMC_RUN_NT
-#define IPK_KMC_RUN_NT 0         // value loads of the run form with the non-temporal hint (1, as km_write_c_kernel) or without (0): a line shared by two blocks
-                                 // of a run is read again microseconds later by the SAME workgroup, and evict-first lines were gone by then (L2 hit rate 43 %
-                                 // against 64 %, HBM reads + 58 % at cfg4: 15.6 against 14.6 ms; equal at a cfg3 share)
+#define IPK_KMC_RUN_NT 1         // value loads of the run form with the non-temporal hint (1, as km_write_c_kernel) or without (0).  Where the run form is used
+                                 // (up to 128 groups) the hint is equal or slightly ahead (cfg3 share, three alternations: 2.81-2.87 against 2.82-3.10 ms);
+                                 // forced at cfg4 it loses -- a line shared by two blocks of a run is read again microseconds later by the SAME workgroup, and
+                                 // evict-first lines were gone by then (L2 hit rate 43 % against 64 %, HBM reads + 58 %: 15.6 against 14.6 ms)
 #endif
 #ifndef IPK_KMC_WPE
 #define IPK_KMC_WPE 1            // 1: registers bounded for four wavefronts per SIMD (four workgroups per CU, as km_write_c_kernel)
