@@ -166,6 +166,29 @@ def test_full_size_matrices_sampled(engine):
     check_against_oracle(engine, mats, [0, 0, 1, 1, 2, 2], 10, co.log_threshold(1.5, 4, 10), device=True)
 
 
+def test_full_size_k12_sampled(engine):
+    """BASELINE cfg3 shape (10 000 sites, k=12) on two groups: the row-per-lane scoring kernel, the persistent reduce of 128-KB slices and
+    the compressed writers, bit-exact vs the oracle -- per-branch sets and the key-major database (entries of a k-mer in group order)."""
+    from ipk_amd import distributed as D
+    mats = synth_matrices(4, 10000, 4, 0.05, 4212)
+    groups = np.array([7, 7, 3, 3], dtype=np.uint32)
+    eps = co.log_threshold(1.5, 4, 12)
+    check_against_oracle(engine, mats, groups, 12, eps, device=True)
+    db, parts = D.build_db_shard(engine, mats, groups, 12, eps, 4)
+    ref = {}
+    for gid in (7, 3):
+        keys, scores, _ = co.explore_group(mats[groups == gid], 12, eps)
+        for kk, sc in zip(keys.tolist(), scores.view(np.uint32).tolist()):
+            ref.setdefault(kk, []).append((gid, sc))
+    dk, off = db.keys(), db.key_offsets().astype(np.int64)
+    br, sc = db.entries()
+    assert len(dk) == len(ref) and db.num_entries == sum(len(v) for v in ref.values())
+    rng = np.random.default_rng(3)
+    for i in rng.integers(0, len(dk), size=3000).tolist():
+        assert [(int(b), int(x)) for b, x in zip(br[off[i]:off[i + 1]], sc[off[i]:off[i + 1]].view(np.uint32))] == ref[int(dk[i])]
+    db.free(); parts.free()
+
+
 def test_full_size_aa_sampled(engine):
     mats = synth_matrices(2, 3000, 20, 0.03, 43)
     check_against_oracle(engine, mats, [0, 0], 6, co.log_threshold(1.5, 20, 6), device=True)
