@@ -45,42 +45,45 @@ __global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            // The chain of float additions IS the algorithm (a scan would round differently): what can be cut is everything
-            // around it -- sixteen maxima per LDS round trip (four 16-byte reads issued together, the next sixteen already in
-            // flight while these are added), the sums written back the same way.
+            // The chain of float additions IS the algorithm (a scan would round differently).  A bare chain of dependent v_add_f32 costs
+            // 4.0 ns per addition on this part (tools/micro_addchain.hip); until round 4 this loop took 9.5-10: the sums went back to LDS
+            // and every trip waited for those writes (s_waitcnt lgkmcnt(0)) before its next reads.  Now the adding lane only READS LDS --
+            // sixteen maxima per round trip, three register sets so that a set's reads are two sets (128 ns of additions) old when they
+            // are needed -- and stores the sums straight to best[] (plain 4-byte stores: nothing ever waits for them).
             float acc = carry;
-            float4* c4 = reinterpret_cast<float4*>(cm);
+            const float4* c4 = reinterpret_cast<const float4*>(cm);
+            float* dst = b + c0 + 1;
             const uint32_t n16 = n / 16;
-            // sixteen sums in place; two register sets take turns (A is added while B's reads are in flight and the other way
-            // round), spelled out so that no set is ever copied into the other
-            auto add16 = [&](float4& v0, float4& v1, float4& v2, float4& v3) {
-                v0.x = acc + v0.x; v0.y = v0.x + v0.y; v0.z = v0.y + v0.z; v0.w = v0.z + v0.w;
-                v1.x = v0.w + v1.x; v1.y = v1.x + v1.y; v1.z = v1.y + v1.z; v1.w = v1.z + v1.w;
-                v2.x = v1.w + v2.x; v2.y = v2.x + v2.y; v2.z = v2.y + v2.z; v2.w = v2.z + v2.w;
-                v3.x = v2.w + v3.x; v3.y = v3.x + v3.y; v3.z = v3.y + v3.z; v3.w = v3.z + v3.w;
-                acc = v3.w;
+            auto add16 = [&](const float4& v0, const float4& v1, const float4& v2, const float4& v3, float* o) {
+                float s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, sa, sb, sc, sd, se, sf;
+                s0 = acc + v0.x; s1 = s0 + v0.y; s2 = s1 + v0.z; s3 = s2 + v0.w;
+                s4 = s3 + v1.x; s5 = s4 + v1.y; s6 = s5 + v1.z; s7 = s6 + v1.w;
+                s8 = s7 + v2.x; s9 = s8 + v2.y; sa = s9 + v2.z; sb = sa + v2.w;
+                sc = sb + v3.x; sd = sc + v3.y; se = sd + v3.z; sf = se + v3.w;
+                acc = sf;
+                o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = s5; o[6] = s6; o[7] = s7;
+                o[8] = s8; o[9] = s9; o[10] = sa; o[11] = sb; o[12] = sc; o[13] = sd; o[14] = se; o[15] = sf;
             };
-            float4 a0, a1, a2, a3, b0, b1, b2, b3;
-            if (n16) { a0 = c4[0]; a1 = c4[1]; a2 = c4[2]; a3 = c4[3]; }
+            float4 r[3][4];
+#pragma unroll
+            for (uint32_t s_ = 0; s_ < 2; ++s_)
+                if (s_ < n16) { r[s_][0] = c4[4 * s_]; r[s_][1] = c4[4 * s_ + 1]; r[s_][2] = c4[4 * s_ + 2]; r[s_][3] = c4[4 * s_ + 3]; }
             uint32_t q = 0;
-            for (; q + 2 <= n16; q += 2) {
-                b0 = c4[4 * q + 4]; b1 = c4[4 * q + 5]; b2 = c4[4 * q + 6]; b3 = c4[4 * q + 7];
-                add16(a0, a1, a2, a3);
-                c4[4 * q] = a0; c4[4 * q + 1] = a1; c4[4 * q + 2] = a2; c4[4 * q + 3] = a3;
-                if (q + 2 < n16) { a0 = c4[4 * q + 8]; a1 = c4[4 * q + 9]; a2 = c4[4 * q + 10]; a3 = c4[4 * q + 11]; }
-                add16(b0, b1, b2, b3);
-                c4[4 * q + 4] = b0; c4[4 * q + 5] = b1; c4[4 * q + 6] = b2; c4[4 * q + 7] = b3;
+            for (; q + 3 <= n16; q += 3) {
+#pragma unroll
+                for (uint32_t u = 0; u < 3; ++u) {
+                    const uint32_t nx = q + u + 2;                               // the set two ahead goes into the registers just freed
+                    if (nx < n16) { r[(u + 2) % 3][0] = c4[4 * nx]; r[(u + 2) % 3][1] = c4[4 * nx + 1]; r[(u + 2) % 3][2] = c4[4 * nx + 2]; r[(u + 2) % 3][3] = c4[4 * nx + 3]; }
+                    add16(r[u][0], r[u][1], r[u][2], r[u][3], dst + 16 * (q + u));
+                }
             }
-            if (q < n16) {
-                add16(a0, a1, a2, a3);
-                c4[4 * q] = a0; c4[4 * q + 1] = a1; c4[4 * q + 2] = a2; c4[4 * q + 3] = a3;
-            }
-            for (uint32_t j = n16 * 16; j < n; ++j) { acc += cm[j]; cm[j] = acc; }
+            // (q is a multiple of 3: the one or two sets left sit in r[0], r[1], their reads issued above)
+            if (q < n16) add16(r[0][0], r[0][1], r[0][2], r[0][3], dst + 16 * q);
+            if (q + 1 < n16) add16(r[1][0], r[1][1], r[1][2], r[1][3], dst + 16 * (q + 1));
+            for (uint32_t j = n16 * 16; j < n; ++j) { acc += cm[j]; dst[j] = acc; }
             carry = acc;
         }
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) b[c0 + j + 1] = cm[j];
-        __syncthreads();
+        __syncthreads();                                   // cm[] is refilled by the next chunk of sites
     }
 }
 
