@@ -14,16 +14,18 @@ template <int SIGMA>
 __global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict__ logp, uint32_t sites,
                                                          float* __restrict__ best)
 {
-    constexpr int CH = 4096;
-    __shared__ __align__(16) float cm[CH];
-    __shared__ float carry;
+    // Two buffers of column maxima: while lane 0 of wavefront 0 adds its way through one chunk of sites, wavefronts 1..3 compute the
+    // next chunk's maxima (round 4: the chain used to wait for every chunk's maxima, all 256 threads for the chain in turn).
+    constexpr int CH = 2048;
+    __shared__ __align__(16) float cmbuf[2][CH];
     const uint32_t mat = blockIdx.x;
     const float* m = logp + (size_t)mat * sites * SIGMA;
     float* b = best + (size_t)mat * (sites + 1);
-    if (threadIdx.x == 0) { carry = 0.0f; b[0] = 0.0f; }
-    for (uint32_t c0 = 0; c0 < sites; c0 += CH) {
+    if (threadIdx.x == 0) b[0] = 0.0f;
+    float carry = 0.0f;                                      // (thread 0's)
+    auto maxima = [&](uint32_t c0, float* cmw, uint32_t t0, uint32_t nt) {
         const uint32_t n = min((uint32_t)CH, sites - c0);
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        for (uint32_t j = t0; j < n; j += nt) {
             const float4* col = reinterpret_cast<const float4*>(m + (size_t)(c0 + j) * SIGMA);
             float largest;
             {
@@ -41,9 +43,18 @@ __global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict
                 if (largest < v.z) largest = v.z;
                 if (largest < v.w) largest = v.w;
             }
-            cm[j] = largest;
+            cmw[j] = largest;
         }
-        __syncthreads();
+    };
+    if (sites > 0) maxima(0, cmbuf[0], threadIdx.x, blockDim.x);
+    uint32_t ci = 0;
+    for (uint32_t c0 = 0; c0 < sites; c0 += CH, ++ci) {
+        const uint32_t n = min((uint32_t)CH, sites - c0);
+        const float* cm = cmbuf[ci & 1];
+        __syncthreads();                                   // this chunk's maxima are in place; the other buffer is free
+        if (threadIdx.x >= 64) {
+            if (c0 + CH < sites) maxima(c0 + CH, cmbuf[(ci + 1) & 1], threadIdx.x - 64, blockDim.x - 64);
+        } else
         if (threadIdx.x == 0) {
             // The chain of float additions IS the algorithm (a scan would round differently).  A bare chain of dependent v_add_f32 costs
             // 4.0 ns per addition on this part (tools/micro_addchain.hip); until round 4 this loop took 9.5-10: the sums went back to LDS
@@ -83,7 +94,6 @@ __global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict
             for (uint32_t j = n16 * 16; j < n; ++j) { acc += cm[j]; dst[j] = acc; }
             carry = acc;
         }
-        __syncthreads();                                   // cm[] is refilled by the next chunk of sites
     }
 }
 
