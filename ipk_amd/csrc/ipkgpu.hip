@@ -1081,7 +1081,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     sp.eps = pl.eps;
     sp.pool = nullptr; sp.pool_cap = 0; sp.pool_next = nullptr; sp.desc = nullptr; sp.pool_ovf = nullptr; sp.pre_chunks = 0;
     sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot;
-    sp.flags = 0;
+    sp.flags = (uint32_t)(ctx->opt_flags) & 4u;      // (bit 2: list building only -- timing experiments)
     xp.cnt = ctx->gbcnt.as<uint32_t>();
     xp.off = ctx->gboff.as<uint64_t>();
     xp.stride = stride;

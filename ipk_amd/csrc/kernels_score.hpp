@@ -1246,6 +1246,7 @@ __global__ __launch_bounds__(NW * 64) void score_xp_kernel(XpParams xp)
                 continue;
             }
             if (nL == 0 || nR == 0) continue;
+            if (p.flags & 4u) continue;                                        // diagnostics: list building only (nothing is counted or written)
             nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)nL);            // wave-uniform by construction: keep them scalar
             nR = (uint32_t)__builtin_amdgcn_readfirstlane((int)nR);
             // R sorted by score, descending (rank by counting, in place; ties by position).  fl(a + b) is monotone
