@@ -378,6 +378,13 @@ int ipkgpu_db_write(ipkgpu_ctx* ctx, ipkgpu_db* db, const ipkgpu_db_header* head
 int ipkgpu_db_write_host(const ipkgpu_db_header* header, uint64_t n_keys, const uint32_t* keys, const uint64_t* key_offsets,
                          const uint32_t* entries, const float* filter_values, const uint32_t* order, const char* path,
                          uint64_t* bytes_written);
+/* The positioned database of ipk-aa-pos (KEEP_POSITIONS: db_builder.cpp:655-662,687-689; branch_group.cpp:73-86): as
+ * ipkgpu_db_write_host, with positions[n] = the window position that goes with every entry's score (ipkgpu_score_groups_positions),
+ * the header's positions flag set and entries of (branch, score, position).  The position's width in the file (u16) is a guess like
+ * the rest of the layout; positions beyond 65535 are refused. */
+int ipkgpu_db_write_host_positions(const ipkgpu_db_header* header, uint64_t n_keys, const uint32_t* keys, const uint64_t* key_offsets,
+                                   const uint32_t* entries, const uint32_t* positions, const float* filter_values, const uint32_t* order,
+                                   const char* path, uint64_t* bytes_written);
 const char* ipkgpu_db_write_last_error(void);
 /* The database file of a multi-GPU build -- the role of merge_stage2 (db_builder.cpp:392-458: batch files opened together,
  * a priority queue on the filter value hands out the k-mer to append next).  Every rank writes ITS shard (the k-mers it owns,

@@ -57,9 +57,9 @@ def ipk():
 @click.option("--ar-only", is_flag=True, help="(ignored)")
 @click.option("--ar-config", type=click.Path(), help="(ignored)")
 @click.option("--keep-positions", is_flag=True,
-              help="(ipk-aa-pos) NOT SUPPORTED by this command: the scoring call exists (ipkgpu_score_groups_positions: per branch, "
-                   "the kept score's window position) but only with per-branch output; the database of positioned entries -- "
-                   "i2l's positioned phylo_kmer and its serialisation, un-vendored -- has no container here, so no file could be written.")
+              help="(ipk-aa-pos; amino acids, one GPU) every database entry carries the window position of its kept score "
+                   "(db_builder.cpp:655-662,687-689): positions are scored per branch (ipkgpu_score_groups_positions) and joined with "
+                   "the key-major database on the host; the entry layout (branch, score, u16 position) is a guess like the rest of the file")
 @click.option("--uncompressed", is_flag=True, help="(ignored, as in the reference)")
 @click.option("--threads", type=int, default=0,
               help="host threads of the probability loader [0 = every core this process may run on, divided among the ranks of a node; the reference's --threads only "
@@ -78,10 +78,11 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
     from ipk_amd import dbfile, distributed
     from ipk_amd.loader import AncestralProbs
 
-    if keep_positions:
-        raise click.UsageError("--keep-positions: positions are scored (ipkgpu_score_groups_positions, per-branch output) but there is no "
-                               "database container for positioned entries here (i2l's positioned phylo_kmer is un-vendored); "
-                               "build without the flag")
+    if keep_positions and states == "nucl":
+        raise click.UsageError("--keep-positions is not supported for DNA.")              # ipk.py:281-282
+    if keep_positions and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise click.UsageError("--keep-positions: the positioned database is assembled by ONE process (positions are scored per branch, "
+                               "ipkgpu_score_groups_positions, and joined with the key-major database on the host); run without torchrun")
     if merge_branches:
         raise click.UsageError("--merge-branches is not supported (the reference only guards it, main.cpp:31-37)")
     from ipk_amd import tree as T
@@ -177,7 +178,33 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
         db.filter_mif0(eng, n_nodes, ipk_amd.score_threshold(omega, sigma, k))
     t_filter = time.time() - t0
     t0 = time.time()
-    if filter_ == "mif0":
+    if keep_positions:
+        # KEEP_POSITIONS (branch_group.cpp:73-86): the kept score's window position.  The database above has the same scores (the position
+        # only rides along with the max); the per-branch positioned result is joined to it entry by entry on the host.
+        res = eng.score_groups_positions(mats.cpu().numpy() if hasattr(mats, "cpu") else mats, np.array(branches, dtype=np.uint32), k, log_eps)
+        keys_db, off_db = db.keys(), db.key_offsets().astype(np.int64)
+        br_db, sc_db = db.entries()
+        entry_key = np.repeat(keys_db, np.diff(off_db))
+        pos_db = np.empty(len(br_db), dtype=np.uint32)
+        rk, rs, rp = res.keys(), res.scores(), res.positions()
+        for gi, gid in enumerate(res.group_ids.tolist()):
+            a, b = int(res.offsets[gi]), int(res.offsets[gi + 1])
+            sel = np.flatnonzero(br_db == gid)
+            idx = np.searchsorted(rk[a:b], entry_key[sel])
+            if len(sel) != b - a or not np.array_equal(rk[a:b][idx], entry_key[sel]) or \
+               not np.array_equal(rs[a:b][idx].view(np.uint32), sc_db[sel].view(np.uint32)):
+                raise click.ClickException("positioned scoring and the database disagree (internal error)")
+            pos_db[sel] = rp[a:b][idx]
+        res.free()
+        if filter_ == "mif0":
+            fv_p, order_p = db.filter_values(), db.filter_order()
+        else:
+            fv_p = (dbfile.splitmix_unit(keys_db) if db.num_keys else np.zeros(0)).astype(np.float32)
+            order_p = np.argsort(dbfile.filter_sort_code(fv_p, keys_db), kind="stable")
+
+        def write_shard(file):
+            dbfile.write_db_positions(file, seq_name, tree_index, newick, k, omega, keys_db, db.key_offsets(), br_db, sc_db, pos_db, fv_p, order_p)
+    elif filter_ == "mif0":
         # records packed on the device in filter order and streamed to the file (ipkgpu_db_write): the database itself on one
         # GPU, this rank's shard on several (a shard's header carries only its totals)
         def write_shard(file):
@@ -219,7 +246,7 @@ def build(ar, refalign, reftree, states, verbosity, workdir, write_reduction, al
                    "IPKGPU_BOOST_ARCHIVE_VERSION sets the archive's library version (default 19).  Guessed fields: the protocol-version "
                    "word behind the archive preamble and the positions flag behind the sequence type (position, width, value; "
                    f"IPKGPU_IPK_PROTOCOL_VERSION, now {dbfile.protocol_version()}, 0 = both left out), the widths of the tree index "
-                   "(u64 / f64), filter value (f32) and key (u32).")
+                   "(u64 / f64), filter value (f32) and key (u32)" + (", and the u16 window position of a positioned entry." if keep_positions else "."))
     db.free(); parts.free(); eng.close(); arp.close()
     if world > 1 and own_group:
         dist.destroy_process_group()

@@ -15,6 +15,8 @@
 //             u64 n ; n x { u64 num_nodes ; f64 subtree_branch_length } ; string newick ;
 //             u64 kmer_size ; f32 omega ; u64 total_num_kmers ; u64 total_num_entries
 //   k-mers    per k-mer in filter order: u32 key ; f32 filter_value ; u64 n ; n x { u32 branch ; f32 score }
+//             positioned build (ipk-aa-pos, KEEP_POSITIONS: db_builder.cpp:655-662,687-689; positions flag = 1):
+//             n x { u32 branch ; f32 score ; u16 position } -- the position's width is a GUESS too (i2l's pos_type is un-vendored)
 //
 // Protocol version and positions flag.  A LOADED database answers version() and positions_loaded() (the reference's own
 // ipkdiff compares both: tools/src/diff.cpp:41-46,137-145; the positions check is commented out there as "broken in v0.4.x+"),
@@ -58,6 +60,7 @@ inline uint32_t protocol_version()
 }
 constexpr uint64_t RECORD_HEAD_BYTES = 16;                   // key, filter value, entry count
 constexpr uint64_t ENTRY_BYTES = 8;                          // branch, score
+constexpr uint64_t ENTRY_POS_BYTES = 10;                     // branch, score, position (u16: ASSUMPTION)
 
 IPKFMT_HD inline uint64_t record_bytes(uint64_t n_entries) { return RECORD_HEAD_BYTES + ENTRY_BYTES * n_entries; }
 

@@ -2649,6 +2649,47 @@ int ipkgpu_db_write_host(const ipkgpu_db_header* h, uint64_t n_keys, const uint3
     return IPKGPU_OK;
 }
 
+// The positioned database (ipk-aa-pos: every entry carries the window position of its kept score, db_builder.cpp:655-662,687-689;
+// branch_group.cpp:73-86): header with the positions flag set, entries of (branch, score, position).
+int ipkgpu_db_write_host_positions(const ipkgpu_db_header* h, uint64_t n_keys, const uint32_t* keys, const uint64_t* key_off,
+                                   const uint32_t* entries, const uint32_t* positions, const float* fv, const uint32_t* order,
+                                   const char* path, uint64_t* bytes_written)
+{
+    if (!h || !path || (n_keys && (!keys || !key_off || !fv || !entries || !positions))) { g_write_err = "null argument"; return IPKGPU_ERR_INVALID; }
+    if (ipkfmt::protocol_version() == 0) { g_write_err = "a positioned database needs the positions flag: IPKGPU_IPK_PROTOCOL_VERSION must not be 0"; return IPKGPU_ERR_INVALID; }
+    const uint64_t n_entries = n_keys ? key_off[n_keys] : 0;
+    for (uint64_t i = 0; i < n_entries; ++i)
+        if (positions[i] > 0xFFFFu) { g_write_err = "a window position beyond 65535 does not fit the entry's position field"; return IPKGPU_ERR_INVALID; }
+    FileOut out;
+    out.f = fopen(path, "wb");
+    if (!out.f) { g_write_err = std::string("cannot create ") + path; return IPKGPU_ERR_INVALID; }
+    const std::vector<uint8_t> head = ipkfmt::file_head(h->sequence_type, h->tree_index_size, h->tree_num_nodes, h->tree_subtree_length, h->newick,
+                                                        h->kmer_size, h->omega, n_keys, n_entries, true);
+    uint64_t total = head.size();
+    if (!out.put(head.data(), head.size())) { g_write_err = "write failed"; return IPKGPU_ERR_INVALID; }
+    std::vector<uint8_t> buf;
+    buf.reserve((size_t)16 << 20);
+    for (uint64_t i = 0; i < n_keys; ++i) {
+        const uint64_t k = order ? order[i] : i;
+        const uint64_t a = key_off[k], n = key_off[k + 1] - a;
+        uint32_t w[4];
+        uint32_t fb; memcpy(&fb, &fv[k], 4);
+        ipkfmt::record_head(keys[k], fb, n, w);
+        ipkfmt::put(buf, w, sizeof w);
+        for (uint64_t j = a; j < a + n; ++j) {
+            ipkfmt::put(buf, entries + 2 * j, 8);
+            ipkfmt::put_v<uint16_t>(buf, (uint16_t)positions[j]);
+        }
+        if (buf.size() >= ((size_t)15 << 20)) { if (!out.put(buf.data(), buf.size())) { g_write_err = "write failed"; return IPKGPU_ERR_INVALID; } total += buf.size(); buf.clear(); }
+    }
+    if (!out.put(buf.data(), buf.size())) { g_write_err = "write failed"; return IPKGPU_ERR_INVALID; }
+    total += buf.size();
+    if (fclose(out.f) != 0) { out.f = nullptr; g_write_err = "close failed"; return IPKGPU_ERR_INVALID; }
+    out.f = nullptr;
+    if (bytes_written) *bytes_written = total;
+    return IPKGPU_OK;
+}
+
 int ipkgpu_db_write(ipkgpu_ctx* ctx, ipkgpu_db* db, const ipkgpu_db_header* h, const char* path, uint64_t* bytes_written)
 {
     if (!ctx) return IPKGPU_ERR_INVALID;

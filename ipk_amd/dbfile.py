@@ -13,7 +13,7 @@ import numpy as np
 
 from .engine import IpkGpuError, load_library
 
-ABI_SYMBOLS = ["ipkgpu_db_write", "ipkgpu_db_write_host", "ipkgpu_db_write_last_error", "ipkgpu_db_write_time_s",
+ABI_SYMBOLS = ["ipkgpu_db_write", "ipkgpu_db_write_host", "ipkgpu_db_write_host_positions", "ipkgpu_db_write_last_error", "ipkgpu_db_write_time_s",
                "ipkgpu_db_merge_files", "ipkgpu_db_merge_last_error", "ipkgpu_db_protocol_version"]
 _bound = False
 
@@ -33,6 +33,9 @@ def _lib():
         L.ipkgpu_db_write_host.restype = C.c_int
         L.ipkgpu_db_write_host.argtypes = [C.POINTER(_Header), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_char_p, C.POINTER(C.c_uint64)]
+        L.ipkgpu_db_write_host_positions.restype = C.c_int
+        L.ipkgpu_db_write_host_positions.argtypes = [C.POINTER(_Header), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]
         L.ipkgpu_db_write_last_error.restype = C.c_char_p
         L.ipkgpu_db_write_last_error.argtypes = []
         L.ipkgpu_db_write_time_s.restype = C.c_double
@@ -99,6 +102,30 @@ def write_db(path, sequence_type, tree_index, newick, kmer_size, omega, keys, ke
     return int(n.value)
 
 
+def write_db_positions(path, sequence_type, tree_index, newick, kmer_size, omega, keys, key_offsets, branches, scores, positions,
+                       filter_values, order):
+    """ipkgpu_db_write_host_positions: the positioned database of ipk-aa-pos -- as write_db, every entry with the window position of
+    its kept score (db_builder.cpp:655-662,687-689)."""
+    L = _lib()
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    off = np.ascontiguousarray(key_offsets, dtype=np.uint64)
+    ent = np.empty((len(branches), 2), dtype=np.uint32)
+    ent[:, 0] = np.asarray(branches, dtype=np.uint32)
+    ent[:, 1] = np.asarray(scores, dtype=np.float32).view(np.uint32)
+    pos = np.ascontiguousarray(positions, dtype=np.uint32)
+    fv = np.ascontiguousarray(filter_values, dtype=np.float32)
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    if len(off) == 0:
+        off = np.zeros(1, np.uint64)
+    h = _header(sequence_type, tree_index, newick, kmer_size, omega)
+    n = C.c_uint64()
+    rc = L.ipkgpu_db_write_host_positions(C.byref(h), len(keys), keys.ctypes.data, off.ctypes.data, ent.ctypes.data, pos.ctypes.data,
+                                          fv.ctypes.data, order.ctypes.data, str(path).encode(), C.byref(n))
+    if rc != 0:
+        raise IpkGpuError(rc, L.ipkgpu_db_write_last_error().decode())
+    return int(n.value)
+
+
 def protocol_version():
     """What the writers put behind the archive preamble (0: no protocol word, no positions flag); ipk_format.hpp."""
     return int(_lib().ipkgpu_db_protocol_version())
@@ -143,6 +170,17 @@ def read_db(path, as_arrays=False, protocol=None):
     hdr = dict(sequence_type=st, tree_index=[(int(a), float(b)) for a, b in ti], newick=newick, kmer_size=k, omega=omega,
                total_num_kmers=nk, total_num_entries=ne, library_version=lib_version, protocol_version=proto,
                positions_loaded=positions)
+    if positions:
+        # records of 16 + 10 n bytes: key, filter value, n, then n x (u32 branch, f32 score, u16 position)
+        recs, q = [], p
+        ent_t = np.dtype([("b", "<u4"), ("s", "<f4"), ("p", "<u2")])
+        for _ in range(nk):
+            key, fvb, cnt = struct.unpack_from("<IfQ", buf, q)
+            e = np.frombuffer(buf, dtype=ent_t, count=cnt, offset=q + 16)
+            recs.append((key, fvb, e["b"].copy(), e["s"].copy(), e["p"].astype(np.uint32)))
+            q += 16 + 10 * cnt
+        assert q == len(buf) and sum(len(r[2]) for r in recs) == ne, "body size does not match the header's totals"
+        return hdr, recs
     body = np.frombuffer(buf[p:], dtype="<u4") if (len(buf) - p) % 4 == 0 else None
     assert body is not None and len(body) == 4 * nk + 2 * ne, "body size does not match the header's totals"
     # record starts: head of 4 words, then 2 words per entry -- walk the counts

@@ -54,6 +54,40 @@ def test_cli_build_end_to_end(tmp_path):
     assert all(recs[i][1] <= recs[i + 1][1] for i in range(len(recs) - 1))
 
 
+@pytest.mark.gpu
+def test_cli_keep_positions(tmp_path):
+    """`ipk.py build --keep-positions --states amino` (ipk-aa-pos): every entry of the database carries the window position that goes
+    with its kept score -- the larger score wins, equal scores keep the EARLIER window (branch_group.cpp:73-86) -- checked against the
+    oracle's positioned groups; DNA is refused as the reference's wrapper refuses it (ipk.py:281-282)."""
+    ar_dir = tmp_path / "AR"; ar_dir.mkdir()
+    labels = [f"{i}_X{j}" for i in range(3) for j in range(2)]
+    write_probs(ar_dir / "ar.raxml.ancestralProbs", 20, labels, 30, 5, extras=False)
+    with open(tmp_path / "map.tsv", "w") as fh:
+        for i, lab in enumerate(labels):
+            fh.write(f"{lab}\t{4 + i // 2}\n")
+    out = tmp_path / "DBpos.ipk"
+    res = CliRunner().invoke(cli.ipk, ["build", "-w", str(tmp_path), "--ar-dir", str(ar_dir), "--mapping", str(tmp_path / "map.tsv"), "-s", "amino",
+                                       "-k", "4", "--omega", "1.5", "-o", str(out), "--num-tree-nodes", "7", "--keep-positions"])
+    assert res.exit_code == 0, (res.output, res.exception)
+    hdr, recs = dbfile.read_db(out)
+    assert hdr["positions_loaded"] is True and hdr["sequence_type"] == "AA"
+    from oracle import ar_oracle
+    mats, _ = ar_oracle.read_file(ar_dir / "ar.raxml.ancestralProbs", 20)
+    eps = co.log_threshold(1.5, 20, 4)
+    full = {}
+    for g in range(3):
+        keys, scores, pos, _ = co.explore_group_pos(np.stack([mats[labels[2 * g]], mats[labels[2 * g + 1]]]), 4, eps)
+        for kk, sc, pp in zip(keys.tolist(), scores.view(np.uint32).tolist(), pos.tolist()):
+            full.setdefault(kk, []).append((4 + g, sc, pp))
+    assert hdr["total_num_kmers"] == len(full) and hdr["total_num_entries"] == sum(len(v) for v in full.values())
+    for key, fv, br, sc, pos in recs:
+        assert [(int(b), int(s), int(p)) for b, s, p in zip(br, sc.view(np.uint32), pos)] == full[key]
+    assert all(recs[i][1] <= recs[i + 1][1] for i in range(len(recs) - 1))
+    bad = CliRunner().invoke(cli.ipk, ["build", "-w", str(tmp_path), "--ar-dir", str(ar_dir), "--mapping", str(tmp_path / "map.tsv"),
+                                       "-k", "4", "-o", str(out), "--keep-positions"])
+    assert bad.exit_code != 0 and "not supported for DNA" in bad.output
+
+
 def _cli_rank(rank, world, port, tmp, args):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0",

@@ -43,6 +43,35 @@ def test_round_trip(tmp_path, monkeypatch, protocol):
         assert [(int(b), int(s)) for b, s in zip(r[2], r[3].view(np.uint32))] == full[r[0]]
 
 
+def test_positioned_round_trip(tmp_path, monkeypatch):
+    """ipk-aa-pos (KEEP_POSITIONS, db_builder.cpp:655-662,687-689): entries of (branch, score, position), the header's positions flag
+    set; a position that does not fit the field, or a layout without the flag, is refused."""
+    rng = np.random.default_rng(11)
+    n = 200
+    keys = np.sort(rng.choice(20 ** 4, size=n, replace=False)).astype(np.uint32)
+    lens = rng.integers(1, 5, size=n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    br = rng.integers(0, 30, size=int(off[-1])).astype(np.uint32)
+    sc = (-rng.random(int(off[-1])) * 4).astype(np.float32)
+    pos = rng.integers(0, 3000, size=int(off[-1])).astype(np.uint32)
+    fv = rng.normal(size=n).astype(np.float32)
+    order = np.argsort(dbfile.filter_sort_code(fv, keys), kind="stable")
+    path = tmp_path / "pos.ipk"
+    nbytes = dbfile.write_db_positions(path, "AA", [(3, 0.5)], "(a,b);", 4, 1.5, keys, off, br, sc, pos, fv, order)
+    assert nbytes == os.path.getsize(path)
+    hdr, recs = dbfile.read_db(path)
+    assert hdr["positions_loaded"] is True and hdr["sequence_type"] == "AA" and hdr["total_num_entries"] == len(br)
+    assert [r[0] for r in recs] == keys[order].tolist()
+    for r, i in zip(recs, order.tolist()):
+        a, b = int(off[i]), int(off[i + 1])
+        assert np.array_equal(r[2], br[a:b]) and np.array_equal(r[3].view(np.uint32), sc[a:b].view(np.uint32)) and np.array_equal(r[4], pos[a:b])
+    with pytest.raises(ipk_amd.IpkGpuError):
+        dbfile.write_db_positions(tmp_path / "x.ipk", "AA", [], "", 4, 1.5, keys, off, br, sc, pos + 70000, fv, order)
+    monkeypatch.setenv("IPKGPU_IPK_PROTOCOL_VERSION", "0")
+    with pytest.raises(ipk_amd.IpkGpuError):
+        dbfile.write_db_positions(tmp_path / "y.ipk", "AA", [], "", 4, 1.5, keys, off, br, sc, pos, fv, order)
+
+
 def test_merge_of_rank_shards_equals_the_single_writer(tmp_path, monkeypatch):
     """Several GPUs: rank r owns the k-mers with code % P == r and its own filter values; merging the shard files by
     (filter value, key) must give the file one GPU writes (ipkgpu_db_merge_files: the role of merge_stage2,
