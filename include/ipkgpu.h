@@ -22,9 +22,10 @@
  * stream that produced them (hipStreamSynchronize / hipEventSynchronize) first.  Every call returns
  * after its device work has finished, so results may be read from any stream afterwards.
  *
- * Not supported (IPKGPU_ERR_INVALID, never a silent fallback): k-mer codes beyond 32 bits -- DNA k > 12,
- * amino acids k > 6 (the reference's command line advertises k <= 31, ipk.py:116; its key type here is
- * u32) -- and the reference's on-disk mode (db_builder.cpp:673-681, branch_group.cpp:109-185: per-group
+ * Not supported (IPKGPU_ERR_INVALID, never a silent fallback): DNA k > 14, amino acids k > 6 (the reference's
+ * command line advertises k <= 31, ipk.py:116; its key type here is u32: DNA k <= 16) -- at DNA k = 13, 14 also a
+ * call in which one window's half list (its 6- / 7-symbol prefixes or suffixes above their threshold) exceeds 6144
+ * entries: near-uniform columns, which real posteriors do not have -- and the reference's on-disk mode (db_builder.cpp:673-681, branch_group.cpp:109-185: per-group
  * files merged later): groups are batched by device memory instead ("workspace_bytes") and the k-mer-keyed
  * merge of batches / ranks runs on the device (ipkgpu_merge_parts*).
  */
@@ -120,7 +121,7 @@ uint32_t ipkgpu_bits_per_symbol(uint32_t sigma);
 /* ipk::kmer_batch -- branch_group.cpp:104-107. */
 size_t ipkgpu_kmer_batch(uint32_t key, size_t n_ranges);
 
-/* Largest supported k for an alphabet (DNA: 12, AA: 6); 0 for unsupported sigma. */
+/* Largest supported k for an alphabet (DNA: 14, AA: 6); 0 for unsupported sigma. */
 uint32_t ipkgpu_max_k(uint32_t sigma);
 
 /* ---- the hot path ---------------------------------------------------------------------- */

@@ -41,7 +41,7 @@ def ipk():
 @click.option("--write-reduction", type=click.Path(), help="(ignored)")
 @click.option("-a", "--alpha", type=float, default=1.0, show_default=True, help="(ignored) AR gamma shape")
 @click.option("-c", "--categories", type=int, default=4, show_default=True, help="(ignored) AR rate categories")
-@click.option("-k", "--k", "k", type=int, default=8, show_default=True, help="k-mer length (DNA <= 12, AA <= 6 on this engine)")
+@click.option("-k", "--k", "k", type=int, default=8, show_default=True, help="k-mer length (DNA <= 14, AA <= 6 on this engine)")
 @click.option("-m", "--model", default=None, help="(ignored) AR model")
 @click.option("--convert-uo", is_flag=True, help="(ignored)")
 @click.option("--no-reduction", is_flag=True, help="(ignored)")

@@ -299,6 +299,10 @@ static void ctx_release(ipkgpu_ctx* ctx, void* p)
     else (void)hipFree(p);
 }
 
+// Kernels that give a slot (or a key) a whole wavefront are launched over at most this many items at a time: a HIP launch takes fewer than
+// 2^32 threads, and 4^13 slots x 64 lanes is exactly that.
+static constexpr uint64_t WAVE_PER_ITEM_SPAN = 1ull << 24;
+
 // A block of at least min_bytes, preferably want_bytes: a cached block that holds min_bytes is taken whole (*got = its size) --
 // the result buffer of the previous, equally shaped call serves the next one without a new hipMalloc.
 static hipError_t ctx_alloc_atleast(ipkgpu_ctx* ctx, void** out, size_t min_bytes, size_t want_bytes, size_t* got)
@@ -326,7 +330,7 @@ static hipError_t ctx_alloc_atleast(ipkgpu_ctx* ctx, void** out, size_t min_byte
 extern "C" {
 
 uint32_t ipkgpu_bits_per_symbol(uint32_t sigma) { return sigma == 4 ? 2u : sigma == 20 ? 5u : 0u; }
-uint32_t ipkgpu_max_k(uint32_t sigma) { return sigma == 4 ? 12u : sigma == 20 ? 6u : 0u; }
+uint32_t ipkgpu_max_k(uint32_t sigma) { return sigma == 4 ? 14u : sigma == 20 ? 6u : 0u; }
 size_t ipkgpu_kmer_batch(uint32_t key, size_t n_ranges) { return n_ranges ? key % n_ranges : 0; }
 
 float ipkgpu_log_threshold(float omega, uint32_t sigma, uint32_t k)
@@ -474,7 +478,7 @@ int launch_overflow(ipkgpu_ctx* ctx, const ScoreParams& p)
         (void)ctx; (void)p;
         return IPKGPU_OK;                           // lists can never overflow
     } else {
-        constexpr size_t lds = TileGeo<SIGMA, K, 1>::HEAD_BYTES + (size_t)wave_scratch_entries<SIGMA, K, 1 << 30>() * 8;
+        constexpr size_t lds = TileGeo<SIGMA, K, 1>::HEAD_BYTES + (size_t)wave_scratch_entries<SIGMA, K, big_capf<SIGMA, K>()>() * 8;
         static_assert(lds <= 160 * 1024, "big-list LDS budget");
         auto kern = score_overflow_kernel<SIGMA, K, POS>;
         if (lds > 64 * 1024)
@@ -500,6 +504,7 @@ template <int SIGMA, int K> constexpr uint32_t stream_tbl()
 {
     constexpr uint64_t T = ipow(SIGMA, K);
     if (Geo<SIGMA, K, 1 << 30>::DIRECT) return 0;                       // sigma^k <= 64: nothing to gain
+    if (SIGMA == 4 && K >= 13) return 0;                                // (a wavefront's 2048+ open chunks do not fit LDS: the exact partition takes over, xp_tbl)
     if (SIGMA == 4) return T <= 16384 ? (uint32_t)T : (K <= 10 ? 16384u : 32768u);
     if (K <= 3) return (uint32_t)T;                                     // 400, 8000
     if (K <= 5) return 32000u;                                          // 20^4 = 5 x 32000, 20^5 = 100 x 32000
@@ -540,7 +545,7 @@ int launch_stream_overflow(ipkgpu_ctx* ctx, const StreamParams& sp)
         return IPKGPU_OK;                           // lists can never overflow
     } else {
         constexpr uint32_t NB = (uint32_t)((ipow(SIGMA, K) + TBL - 1) / TBL);
-        constexpr size_t lds = TileGeo<SIGMA, K, 1>::HEAD_BYTES + (size_t)wave_scratch_entries<SIGMA, K, 1 << 30>() * 8 +
+        constexpr size_t lds = TileGeo<SIGMA, K, 1>::HEAD_BYTES + (size_t)wave_scratch_entries<SIGMA, K, big_capf<SIGMA, K>()>() * 8 +
                                (size_t)OVF_NW * 2 * NB * SUB * 4;
         static_assert(lds + 64 <= 160 * 1024, "big-list (stream) LDS budget");
         auto kern = score_overflow_stream_kernel<SIGMA, K, TBL>;
@@ -677,6 +682,7 @@ template <int SIGMA, int K> constexpr int xp_nw() { return SIGMA == 20 ? IPK_XPN
 template <int SIGMA, int K> constexpr uint32_t xp_tbl()
 {
     if (SIGMA == 20 && K == 6) return 16000u;                           // 4000 buckets per group; 64 KB reduce tables: two workgroups per CU
+    if (SIGMA == 4 && K >= 13) return 32768u;                           // DNA k = 13, 14: 2048 / 8192 buckets per group (TBL a multiple of 4^7 = a row's code range)
     return stream_tbl<SIGMA, K>();
 }
 template <int SIGMA, int K> uint32_t xp_nb() {
@@ -719,7 +725,7 @@ int launch_xp_overflow(ipkgpu_ctx* ctx, const XpParams& xp)
         (void)ctx; (void)xp;
         return IPKGPU_OK;                           // lists can never overflow
     } else {
-        constexpr size_t lds = TileGeo<SIGMA, K, 1>::HEAD_BYTES + (size_t)wave_scratch_entries<SIGMA, K, 1 << 30>() * 8;
+        constexpr size_t lds = TileGeo<SIGMA, K, 1>::HEAD_BYTES + (size_t)wave_scratch_entries<SIGMA, K, big_capf<SIGMA, K>()>() * 8;
         static_assert(lds + 64 <= 160 * 1024, "big-list (exact partition) LDS budget");
         auto kern = score_overflow_xp_kernel<SIGMA, K, TBL, WRITE>;
         if (lds > 64 * 1024)
@@ -759,6 +765,7 @@ template <int SIGMA, int K> uint32_t xp_tbl_value() { return xp_tbl<SIGMA, K>();
                 case 5: EXPR_MACRO(4, 5); case 6: EXPR_MACRO(4, 6); case 7: EXPR_MACRO(4, 7); \
                 case 8: EXPR_MACRO(4, 8); case 9: EXPR_MACRO(4, 9); case 10: EXPR_MACRO(4, 10); \
                 case 11: EXPR_MACRO(4, 11); case 12: EXPR_MACRO(4, 12);                \
+                case 13: EXPR_MACRO(4, 13); case 14: EXPR_MACRO(4, 14);                \
             }                                                                          \
         } else if ((SIGMA_V) == 20) {                                                  \
             switch (K_V) {                                                             \
@@ -1080,7 +1087,7 @@ int score_batch_xp(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uint3
     sp.sites = pl.sites; sp.nwin = pl.nwin; sp.tiles_per_mat = tiles_per_mat; sp.S = S;
     sp.eps = pl.eps;
     sp.pool = nullptr; sp.pool_cap = 0; sp.pool_next = nullptr; sp.desc = nullptr; sp.pool_ovf = nullptr; sp.pre_chunks = 0;
-    sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot;
+    sp.emitted = p.emitted; sp.ovf_queue = p.ovf_queue; sp.ovf_count = p.ovf_count; sp.mat_slot = p.mat_slot; sp.big_ovf = p.big_ovf;
     sp.flags = (uint32_t)(ctx->opt_flags) & 4u;      // (bit 2: list building only -- timing experiments)
     xp.cnt = ctx->gbcnt.as<uint32_t>();
     xp.off = ctx->gboff.as<uint64_t>();
@@ -1230,6 +1237,19 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     p.ovf_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 16);
     p.flags = (uint32_t)(ctx->opt_variant == 99 ? 1 : 0);
     p.mask = nullptr; p.mask_words = 0;
+    // capped big-list capacity (DNA k >= 13, kernels_score.hpp big_capf): the flag word, checked at the end of the batch
+    const bool capped_lists = pl.sigma == 4 && pl.k >= 13;
+    p.big_ovf = capped_lists ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->small) + 44) : nullptr;
+    if (capped_lists) HIP_TRY(ctx, hipMemsetAsync(p.big_ovf, 0, 4, ctx->stream));
+    auto check_capped = [&]() -> int {
+        if (!capped_lists) return IPKGPU_OK;
+        uint32_t hit = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&hit, p.big_ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (hit) return fail(ctx, IPKGPU_ERR_INVALID, "a window's half list exceeds %d entries: beyond the capacity of this engine at k = %u "
+                                                      "(the lists of k >= 13 are capped; lower omega's reach or k)", BIG_CAP_ENTRIES, pl.k);
+        return IPKGPU_OK;
+    };
     ctx->mask_valid = false;
     ctx->table_compressed = false;
     const uint32_t NBK = stream_buckets(pl.sigma, pl.k);
@@ -1273,7 +1293,7 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->acc_main_ms += sw.ms(a, b);
         ctx->main_kernel = "score_tiles_kernel";
-        return IPKGPU_OK;
+        return check_capped();
     }
 
     // ---- stream variant: pass 1 (append pairs) -> chunk index -> pass 2 (LDS reduce) -> big-list windows
@@ -1281,7 +1301,10 @@ int score_batch_impl(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev, uin
     ctx->mask_words = 2 * ((pl.table_size + 63) / 64);
     RC_TRY(ensure(ctx, ctx->mask, (size_t)gb * ctx->mask_words * 4));
     p.mask = ctx->mask.as<uint32_t>(); p.mask_words = ctx->mask_words;
-    if (use_xp) return score_batch_xp(ctx, pl, logp_dev, gb, nb, p, XNB, xp_compress);
+    if (use_xp) {
+        const int rc = score_batch_xp(ctx, pl, logp_dev, gb, nb, p, XNB, xp_compress);
+        return rc ? rc : check_capped();
+    }
 
     // Segments (workgroups) per group.  More workgroups balance the tail of the persistent kernel, but every
     // wavefront keeps one open chunk per key bucket, so workgroups x waves x buckets must stay well below
@@ -2006,9 +2029,10 @@ int merge_sources(ipkgpu_ctx* ctx, uint32_t sigma, uint32_t k, uint32_t owner, u
     const uint64_t n_total = h_tot[0];
     uint2* dst = nullptr;
     HIP_TRY(ctx, ctx_alloc(ctx, (void**)&dst, std::max<uint64_t>(n_total, 1) * 8));
-    if (slots) {
-        hipLaunchKernelGGL(merge_copy_kernel, dim3((uint32_t)((slots + 3) / 4)), dim3(256), 0, ctx->stream, d_counts, S, slots,
-                           ctx->tmp_c.as<uint64_t>(), d_src, ctx->tmp_b.as<uint64_t>(), dst);
+    for (uint64_t first = 0; first < slots; first += WAVE_PER_ITEM_SPAN) {   // (a wavefront per slot: 4^13 slots in one launch would be 2^32 threads)
+        const uint64_t span = std::min<uint64_t>(WAVE_PER_ITEM_SPAN, slots - first);
+        hipLaunchKernelGGL(merge_copy_kernel, dim3((uint32_t)((span + 3) / 4)), dim3(256), 0, ctx->stream, d_counts, S, slots,
+                           ctx->tmp_c.as<uint64_t>(), d_src, ctx->tmp_b.as<uint64_t>(), dst, first);
     }
     *dst_out = dst;                       // owned by the caller from here on (also on failure)
     *n_total_out = n_total;
@@ -2522,8 +2546,9 @@ int ipkgpu_db_filter_mif0(ipkgpu_ctx* ctx, ipkgpu_db* db, uint64_t total_num_gro
     if (n == 0) return IPKGPU_OK;
     Stopwatch sw(ctx->stream, &ctx->events);
     const int t0 = sw.mark();
-    hipLaunchKernelGGL(mif0_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, ctx->stream, db->d_key_off, db->d_entries, n,
-                       (double)total_num_groups, (double)threshold, db->d_fv64, db->d_fv32);
+    for (uint64_t first = 0; first < n; first += WAVE_PER_ITEM_SPAN)
+        hipLaunchKernelGGL(mif0_kernel, dim3((uint32_t)((std::min<uint64_t>(WAVE_PER_ITEM_SPAN, n - first) + 3) / 4)), dim3(256), 0, ctx->stream,
+                           db->d_key_off, db->d_entries, n, (double)total_num_groups, (double)threshold, db->d_fv64, db->d_fv32, first);
     HIP_TRY(ctx, hipGetLastError());
     // order: ascending filter value (std::sort of kmer_order, db_builder.cpp:284), ties by ascending key
     RC_TRY(ensure(ctx, ctx->tmp_a, n * 8));

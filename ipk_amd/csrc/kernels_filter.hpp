@@ -37,9 +37,9 @@ __device__ __forceinline__ double shannon(double x) { return -x * log2(x); }
 
 __global__ __launch_bounds__(256) void mif0_kernel(const uint64_t* __restrict__ key_off, const uint2* __restrict__ entries,
                                                    uint64_t n_keys, double N, double threshold,
-                                                   double* __restrict__ fv64, float* __restrict__ fv32)
+                                                   double* __restrict__ fv64, float* __restrict__ fv32, uint64_t first)
 {
-    const uint64_t key = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
+    const uint64_t key = first + (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
     if (key >= n_keys) return;
     const uint32_t lane = lane_id();
     const uint64_t a = key_off[key], b = key_off[key + 1];

@@ -920,9 +920,10 @@ __global__ __launch_bounds__(256) void merge_copy_kernel(const uint32_t* const* 
                                                          const uint64_t* __restrict__ goff,      // [S * slots + 1]
                                                          const uint2* const* __restrict__ src,
                                                          const uint64_t* __restrict__ dst_off,   // [slots+1]
-                                                         uint2* __restrict__ dst)
+                                                         uint2* __restrict__ dst,
+                                                         uint64_t first)                         // (a launch covers slots from `first`: grid x block stays below 2^32)
 {
-    const uint64_t q = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t q = first + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= slots) return;
     const uint32_t lane = lane_id();
     uint64_t d = dst_off[q];

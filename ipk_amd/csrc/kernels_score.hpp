@@ -113,6 +113,7 @@ struct ScoreParams {
     uint32_t flags;               // bit 0 (diagnostic builds of bench only): skip the table update
     uint32_t* mask;               // [slots][mask_words] occupancy bits of the tables (bit x % 32 of word x / 32), or null:
     uint64_t mask_words;          //   written by the LDS reduce passes, kept current by the big-list kernel
+    uint32_t* big_ovf = nullptr;  // set when a window's half list exceeds the big-list kernels' capped capacity (big_capf, DNA k >= 13)
 };
 
 // ipk::put (branch_group.cpp:88-101): keep the larger score; the first one wins ties.
@@ -239,12 +240,21 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
 #define IPK_OVF_NW 8
 #endif
 constexpr int OVF_NW = IPK_OVF_NW;
+// Capacity of the big-list kernels' half lists.  Up to DNA k = 12 / AA k = 6 a window's worst-case lists (sigma^ceil(k/2) entries
+// each) fit LDS and nothing can overflow; from DNA k = 13 they do not (2 x 4^7 x 8 B = 256 KB), so the lists are capped at
+// BIG_CAP_ENTRIES and a window whose half list exceeds that raises *big_ovf: the call fails loudly (IPKGPU_ERR_INVALID) instead of
+// dropping k-mers.  (Flat posteriors at low omega can get there; the reference has no such limit -- its lists live in host memory.)
+constexpr int BIG_CAP_ENTRIES = 6144;
+template <int SIGMA, int K> constexpr int big_capf()
+{
+    return (size_t)wave_scratch_entries<SIGMA, K, 1 << 30>() * 8 <= (size_t)136 * 1024 ? (1 << 30) : BIG_CAP_ENTRIES;
+}
 
 template <int SIGMA, int K, bool POS = false>
 __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int CAPF = 1 << 30;
+    constexpr int CAPF = big_capf<SIGMA, K>();
     using TG = TileGeo<SIGMA, K, 1>;
     __shared__ uint32_t sh_n[2];
     float* cols = reinterpret_cast<float*>(smem);
@@ -271,7 +281,8 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
         if (wave == 0) {
             WinCtx c{cols, best, 0};
             uint32_t nL = 0, nR = 0;
-            build_halves<SIGMA, K, CAPF>(c, p.eps, scratch, L, nL, R, nR);      // cannot overflow at full capacity
+            const bool fits = build_halves<SIGMA, K, CAPF>(c, p.eps, scratch, L, nL, R, nR);      // (cannot overflow at full capacity)
+            if (!fits) { nL = 0; nR = 0; if (lane == 0 && p.big_ovf) atomicOr(p.big_ovf, 1u); }   // capped lists (big_capf): the call fails
             if (lane == 0) { sh_n[0] = nL; sh_n[1] = nR; }
         }
         __syncthreads();
@@ -362,6 +373,7 @@ struct StreamParams {
                                    // starts in chunk w * NB + b -- and pool_next starts at pre_chunks (0: every first chunk is drawn)
     uint32_t* tile_next = nullptr; // quad kernel: [groups] next tile of each group -- its S workgroups DRAW their tiles instead of
                                    // owning a fixed range each (nullptr: fixed ranges); set to S before the launch (tile `seg` is a workgroup's first)
+    uint32_t* big_ovf = nullptr;   // set when a window's half list exceeds the big-list kernels' capped capacity (big_capf, DNA k >= 13)
 };
 
 // M with floor(t / n) == (t * M) >> 16 for 0 <= t < 128, 1 <= n <= 64   (M = ceil(65536 / n))
@@ -656,7 +668,7 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_stream_kernel(Stre
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t CH = chunk_pairs<TBL>();
-    constexpr int CAPF = 1 << 30;
+    constexpr int CAPF = big_capf<SIGMA, K>();
     constexpr uint32_t T = ipow(SIGMA, K);
     constexpr uint32_t NB = (T + TBL - 1) / TBL;
     using TG = TileGeo<SIGMA, K, 1>;
@@ -702,7 +714,8 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_stream_kernel(Stre
         if (wave == 0) {
             WinCtx c{cols, best, 0};
             uint32_t nL = 0, nR = 0;
-            build_halves<SIGMA, K, CAPF>(c, p.eps, scratch, L, nL, R, nR);      // cannot overflow at full capacity
+            const bool fits = build_halves<SIGMA, K, CAPF>(c, p.eps, scratch, L, nL, R, nR);      // (cannot overflow at full capacity)
+            if (!fits) { nL = 0; nR = 0; if (lane == 0 && p.big_ovf) atomicOr(p.big_ovf, 1u); }   // capped lists (big_capf): the call fails
             if (lane == 0) { sh_n[0] = nL; sh_n[1] = nR; }
         }
         __syncthreads();
@@ -1400,7 +1413,7 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_xp_kernel(XpParams
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const StreamParams& p = xp.s;
-    constexpr int CAPF = 1 << 30;
+    constexpr int CAPF = big_capf<SIGMA, K>();
     constexpr uint32_t T = ipow(SIGMA, K);
     constexpr uint32_t NB = (T + TBL - 1) / TBL;
     constexpr uint32_t mulR = ipow(SIGMA, K - K / 2);
@@ -1428,7 +1441,8 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_xp_kernel(XpParams
         if (wave == 0) {
             WinCtx c{cols, best, 0};
             uint32_t nL = 0, nR = 0;
-            build_halves<SIGMA, K, CAPF>(c, p.eps, scratch, L, nL, R, nR);      // cannot overflow at full capacity
+            const bool fits = build_halves<SIGMA, K, CAPF>(c, p.eps, scratch, L, nL, R, nR);      // (cannot overflow at full capacity)
+            if (!fits) { nL = 0; nR = 0; if (lane == 0 && p.big_ovf) atomicOr(p.big_ovf, 1u); }   // capped lists (big_capf): the call fails
             if (lane == 0) { sh_n[0] = nL; sh_n[1] = nR; }
         }
         __syncthreads();

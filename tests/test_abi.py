@@ -31,7 +31,7 @@ def test_host_helpers_no_gpu_needed():
     assert abs(ipk_amd.log_threshold(1.5, 4, 10) - (-4.259687)) < 1e-5
     assert ipk_amd.bits_per_symbol(4) == 2 and ipk_amd.bits_per_symbol(20) == 5 and ipk_amd.bits_per_symbol(7) == 0
     assert ipk_amd.kmer_batch(1000003, 32) == 1000003 % 32
-    assert ipk_amd.max_k(4) == 12 and ipk_amd.max_k(20) == 6
+    assert ipk_amd.max_k(4) == 14 and ipk_amd.max_k(20) == 6
 
 
 def test_no_cpu_fallback():

@@ -54,6 +54,47 @@ def test_dna_all_k(engine, k):
     check_against_oracle(engine, mats, [5, 5, 9, 9], k, co.log_threshold(1.5, 4, k))
 
 
+@pytest.mark.parametrize("k,sites", [(13, 48), (14, 40), (13, 300)])
+def test_dna_k13_k14(engine, k, sites):
+    """DNA k = 13, 14 (round 4; the reference accepts k up to seq_traits::max_kmer_length, ipk/src/main.cpp:131): the exact-partition
+    variant with compressed tables over 4^13 / 4^14 keys; per-branch sets and the key-major database against the oracle."""
+    from ipk_amd import distributed as D
+    mats = synth_matrices(4, sites, 4, 0.1, 1300 + k)
+    groups = np.array([5, 5, 9, 9], dtype=np.uint32)
+    eps = co.log_threshold(1.5, 4, k)
+    check_against_oracle(engine, mats, groups, k, eps)
+    ref = {}
+    for gid in (5, 9):
+        keys, scores, _ = co.explore_group(mats[groups == gid], k, eps)
+        for kk, sc in zip(keys.tolist(), scores.view(np.uint32).tolist()):
+            ref.setdefault(kk, []).append((gid, sc))
+    # one batch, then a group per batch: the merge of two batches' parts walks 4^k slots a wavefront each (launched in spans: one launch
+    # of 4^13 x 64 threads is refused by the runtime)
+    for workspace in ((None, 1 << 20) if sites < 100 else (None,)):
+        if workspace:
+            engine.set_option("workspace_bytes", workspace)
+        try:
+            db, parts = D.build_db_shard(engine, mats, groups, k, eps, 4)
+        finally:
+            engine.set_option("workspace_bytes", 8 << 30)
+        dk, off = db.keys(), db.key_offsets().astype(np.int64)
+        br, sc = db.entries()
+        assert len(dk) == len(ref) and db.num_entries == sum(len(v) for v in ref.values())
+        for i in np.random.default_rng(1).integers(0, len(dk), size=2000).tolist():
+            assert [(int(b), int(x)) for b, x in zip(br[off[i]:off[i + 1]], sc[off[i]:off[i + 1]].view(np.uint32))] == ref[int(dk[i])]
+        db.free(); parts.free()
+
+
+def test_k13_lists_beyond_the_capped_capacity_fail_loudly(engine):
+    """From k = 13 the big-list kernels' half lists are capped (6144 entries; 4^7 = 16384 cannot live in LDS): flat columns, where every
+    7-symbol suffix passes, must end in an error, not in a database with k-mers missing."""
+    mats = np.full((2, 14, 4), np.log10(0.25), dtype=np.float32)
+    with pytest.raises(ipk_amd.IpkGpuError):
+        engine.score_groups(mats, np.array([1, 1], dtype=np.uint32), 13, np.float32(-8.0))   # 13 log10(0.25) = -7.83: every k-mer passes
+    # and the context is still usable
+    check_against_oracle(engine, synth_matrices(2, 40, 4, 0.1, 77), [3, 3], 13, co.log_threshold(1.5, 4, 13))
+
+
 @pytest.mark.parametrize("k", list(range(2, 7)))
 def test_aa_all_k(engine, k):
     mats = synth_matrices(3, 20, 20, 0.03, 300 + k)
