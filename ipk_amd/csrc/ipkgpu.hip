@@ -1035,7 +1035,11 @@ int make_plan(ipkgpu_ctx* ctx, const void* logp, uint32_t n_mats, uint32_t sites
     {
         const double ppw = ctx->pairs_per_window > 0 ? ctx->pairs_per_window : 256.0;
         const double pool_per_group = (double)n_mats / (double)pl.n_groups * (double)pl.nwin * ppw * 8.0 * 1.25;
-        const double per_group = (double)pl.table_size * 4.0 + pool_per_group;
+        // (the exact partition ends in compressed tables, in place in the pool: occupancy bits, ranks and value addresses only -- T / 8 +
+        //  T / 16 + T / 8 bytes instead of 4 T; with the dense figure 125 groups of k = 14 were scored in two batches and merged)
+        const uint32_t xnb = xp_buckets(sigma, k);
+        const bool no_dense = xnb != 0 && (ctx->opt_variant == 4 || (ctx->opt_variant == 0 && stream_buckets(sigma, k) == 0));
+        const double per_group = (double)pl.table_size * (no_dense ? 0.3125 : 4.0) + pool_per_group;
         pl.gpb = std::max<uint64_t>(1, (uint64_t)((double)ctx->workspace_bytes / per_group));
     }
     pl.gpb = std::min<uint64_t>(pl.gpb, pl.n_groups);

@@ -13,6 +13,8 @@ mats = synth_matrices(2 * groups, sites, 4, 0.05, 42)
 mg = np.repeat(np.arange(groups, dtype=np.uint32), 2)
 dev = torch.from_numpy(mats).cuda()
 eng = ipk_amd.Engine(0)
+if os.environ.get("IPKGPU_DEBUG_FLAGS"):
+    eng.set_option("debug_flags", int(os.environ["IPKGPU_DEBUG_FLAGS"]))
 from ipk_amd import engine as E
 ks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [12, 13, 14]
 for k in ks:
@@ -24,7 +26,7 @@ for k in ks:
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
         nk, ne = db.num_keys, db.num_entries
         print(f"  pass {it}: {ts[-1]:.1f} ms wall; device total {parts.time_ms(E.T_TOTAL):.1f}, scoring {parts.time_ms(E.T_SCORE):.1f} (count {parts.time_ms(E.T_XP_COUNT):.1f}, "
-              f"write {parts.time_ms(E.T_XP_WRITE):.1f}, reduce {parts.time_ms(E.T_SCORE_REDUCE):.1f}), key-major {parts.time_ms(E.T_COMPACT):.1f} (writer {parts.time_ms(E.T_KM_WRITE):.1f}), db {db.time_ms():.1f}", flush=True)
+              f"batches {parts.time_ms(E.T_SCORE_LAUNCHES):.0f}, write {parts.time_ms(E.T_XP_WRITE):.1f}, reduce {parts.time_ms(E.T_SCORE_REDUCE):.1f}), key-major {parts.time_ms(E.T_COMPACT):.1f} (writer {parts.time_ms(E.T_KM_WRITE):.1f}), db {db.time_ms():.1f}", flush=True)
         if it == 3:
             # filter values over all keys (a wavefront per key, launched in spans of 2^24 keys): sampled keys of every span against the oracle's formula
             from oracle import ipk_oracle as co          # (a diagnostic tool, not the product: the oracle only checks)
