@@ -303,7 +303,7 @@ def main():
         eng.set_option("variant", args.variant)
     if os.environ.get("IPKGPU_VARIANT"):
         eng.set_option("variant", int(os.environ["IPKGPU_VARIANT"]))   # diagnostics only
-    for knob in ("wg_chunks2", "rounds"):                     # tuning experiments only
+    for knob in ("wg_chunks2", "rounds", "kmc_pass", "prefix_mats"):   # tuning experiments only
         if os.environ.get("IPKGPU_" + knob.upper()):
             eng.set_option("debug_" + knob, int(os.environ["IPKGPU_" + knob.upper()]))
     if os.environ.get("IPKGPU_DEBUG_FLAGS"):

@@ -99,7 +99,8 @@ int64_t ipkgpu_debug_exec_violations(ipkgpu_ctx* ctx);
  * their tiles; 9 / 10: the dense key-major writer with tile-by-tile / with line-cut stores whatever the group count; 11: 128-KB
  * table slices reduced by the workgroup-per-slice kernel instead of the persistent one; 12 / 13: the compressed key-major writer
  * per key block / per run of key blocks whatever the group count), "debug_pool_chunks", "debug_pool_limit_bytes",
- * "debug_wg_chunks2", "debug_rounds", "debug_kmc_pass" (groups per pass of the compressed key-major writer) (diagnostics and tests only).
+ * "debug_wg_chunks2", "debug_rounds", "debug_kmc_pass" (groups per pass of the compressed key-major writer),
+ * "debug_prefix_mats" (matrices per workgroup of the prefix-sum kernel: 1, 2, 4, 8; 0 = by the matrix count) (diagnostics and tests only).
  * Every variant yields identical results.  Returns IPKGPU_ERR_INVALID for unknown names.
  *
  * Calls on one context are synchronous, but from its second scoring call on a context waits on its stream ONCE per key-major

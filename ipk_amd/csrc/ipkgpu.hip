@@ -103,6 +103,7 @@ struct ipkgpu_ctx {
     int64_t opt_variant = 0;
     int64_t opt_flags = 0;
     int64_t opt_kmc_pass = 0;            // groups per pass of the compressed key-major writer (0: IPK_KMC_PASS)
+    int64_t opt_prefix_mats = 0;         // matrices per workgroup of prefix_max_kernel (0: by the matrix count; 1, 2, 4, 8: tests)
     int64_t opt_wg_chunks2 = 0;       // tuning knob: overrides IPK_WG_CHUNKS2 (0 = built-in), opt_rounds: IPK_ROUNDS
     int64_t opt_rounds = 0;
     int64_t opt_pool_limit = 0;       // test knob: bytes the pair pool may take (0 = what the device has free)
@@ -419,6 +420,7 @@ int ipkgpu_set_option(ipkgpu_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "debug_wg_chunks2")) { ctx->opt_wg_chunks2 = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_rounds")) { ctx->opt_rounds = value; return IPKGPU_OK; }
     if (!strcmp(name, "debug_kmc_pass")) { ctx->opt_kmc_pass = value; return IPKGPU_OK; }
+    if (!strcmp(name, "debug_prefix_mats")) { ctx->opt_prefix_mats = value; return IPKGPU_OK; }
     return fail(ctx, IPKGPU_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -1053,10 +1055,15 @@ int run_prefix(ipkgpu_ctx* ctx, const Plan& pl, const float* logp_dev)
 {
     RC_TRY(ensure(ctx, ctx->best, (size_t)pl.n_mats * (pl.sites + 1) * 4));
     HIP_TRY(ctx, hipMemsetAsync(ctx->small, 0, 64, ctx->stream));
-    if (pl.sigma == 4)
-        hipLaunchKernelGGL(prefix_max_kernel<4>, dim3(pl.n_mats), dim3(256), 0, ctx->stream, logp_dev, pl.sites, ctx->best.as<float>());
-    else
-        hipLaunchKernelGGL(prefix_max_kernel<20>, dim3(pl.n_mats), dim3(256), 0, ctx->stream, logp_dev, pl.sites, ctx->best.as<float>());
+    // matrices per workgroup: as few as keep the call to one round of workgroups (the kernel's registers allow 7 per CU; 4 leaves room)
+    uint32_t M = 1;
+    while (M < 8 && (pl.n_mats + M - 1) / M > (uint32_t)ctx->num_cu * 4) M *= 2;
+    if (ctx->opt_prefix_mats == 1 || ctx->opt_prefix_mats == 2 || ctx->opt_prefix_mats == 4 || ctx->opt_prefix_mats == 8) M = (uint32_t)ctx->opt_prefix_mats;
+    const dim3 grid((pl.n_mats + M - 1) / M);
+#define IPK_PREFIX(SG, MM) hipLaunchKernelGGL((prefix_max_kernel<SG, MM>), grid, dim3(256), 0, ctx->stream, logp_dev, pl.n_mats, pl.sites, ctx->best.as<float>())
+    if (pl.sigma == 4) { if (M == 1) IPK_PREFIX(4, 1); else if (M == 2) IPK_PREFIX(4, 2); else if (M == 4) IPK_PREFIX(4, 4); else IPK_PREFIX(4, 8); }
+    else { if (M == 1) IPK_PREFIX(20, 1); else if (M == 2) IPK_PREFIX(20, 2); else if (M == 4) IPK_PREFIX(20, 4); else IPK_PREFIX(20, 8); }
+#undef IPK_PREFIX
     HIP_TRY(ctx, hipGetLastError());
     return IPKGPU_OK;
 }

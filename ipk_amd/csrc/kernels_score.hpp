@@ -7,60 +7,70 @@ namespace ipkgpu {
 
 
 // ---- matrix::preprocess (window.cpp:16-27): best[0] = 0, best[j+1] = best[j] + max_i m[j][i] ---
-// One workgroup per matrix.  Column maxima are computed by all lanes (coalesced), the running sum
-// is accumulated by ONE lane in site order -- a parallel scan would round differently, and the
-// rounding noise of this array is part of the reference semantics.
-template <int SIGMA>
-__global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict__ logp, uint32_t sites,
+// Column maxima are computed by all lanes (coalesced), the running sum is accumulated by ONE lane per matrix in site
+// order -- a parallel scan would round differently, and the rounding noise of this array is part of the reference
+// semantics.  A workgroup takes M consecutive matrices: their chains run side by side in lanes
+// 0..M-1 of wavefront 0 (a chain is latency, 4 ns per addition whatever the other lanes do), so that a call's matrices
+// fit one round of workgroups -- with a workgroup per matrix cfg2's 2000 were 7.8 per CU against 7 resident, two rounds:
+// 0.22 ms where a rank's share of 250 took 0.065.
+template <int SIGMA, int M>
+__global__ __launch_bounds__(256) void prefix_max_kernel(const float* __restrict__ logp, uint32_t n_mats, uint32_t sites,
                                                          float* __restrict__ best)
 {
-    // Two buffers of column maxima: while lane 0 of wavefront 0 adds its way through one chunk of sites, wavefronts 1..3 compute the
+    // Two buffers of column maxima: while the chain lanes add their way through one chunk of sites, wavefronts 1..3 compute the
     // next chunk's maxima (round 4: the chain used to wait for every chunk's maxima, all 256 threads for the chain in turn).
-    constexpr int CH = 2048;
-    __shared__ __align__(16) float cmbuf[2][CH];
-    const uint32_t mat = blockIdx.x;
-    const float* m = logp + (size_t)mat * sites * SIGMA;
-    float* b = best + (size_t)mat * (sites + 1);
-    if (threadIdx.x == 0) b[0] = 0.0f;
-    float carry = 0.0f;                                      // (thread 0's)
-    auto maxima = [&](uint32_t c0, float* cmw, uint32_t t0, uint32_t nt) {
+    constexpr int CH = 2048 / M;
+    constexpr int ROW = CH + 4;                              // (the chain lanes' 16-byte reads of their own rows: banks 4 lanes apart)
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8, "matrices per workgroup");
+    __shared__ __align__(16) float cmbuf[2][M][ROW];
+    const uint32_t mat0 = blockIdx.x * M;
+    const uint32_t mv = min((uint32_t)M, n_mats - mat0);     // matrices of this workgroup (host: blockIdx.x * M < n_mats)
+    const bool chain = threadIdx.x < mv;
+    const uint32_t my = mat0 + (chain ? threadIdx.x : 0u);   // the chain lane's matrix
+    float* b = best + (size_t)my * (sites + 1);
+    if (chain) b[0] = 0.0f;
+    float carry = 0.0f;                                      // (the chain lanes')
+    auto maxima = [&](uint32_t c0, float (*cmw)[ROW], uint32_t t0, uint32_t nt) {
         const uint32_t n = min((uint32_t)CH, sites - c0);
-        for (uint32_t j = t0; j < n; j += nt) {
-            const float4* col = reinterpret_cast<const float4*>(m + (size_t)(c0 + j) * SIGMA);
-            float largest;
-            {
-                const float4 v = col[0];
-                largest = v.x;                                  // std::max_element: first largest
-                if (largest < v.y) largest = v.y;
-                if (largest < v.z) largest = v.z;
-                if (largest < v.w) largest = v.w;
-            }
+        for (uint32_t mm = 0; mm < mv; ++mm) {
+            const float* m = logp + ((size_t)(mat0 + mm) * sites + c0) * SIGMA;
+            for (uint32_t j = t0; j < n; j += nt) {
+                const float4* col = reinterpret_cast<const float4*>(m + (size_t)j * SIGMA);
+                float largest;
+                {
+                    const float4 v = col[0];
+                    largest = v.x;                                  // std::max_element: first largest
+                    if (largest < v.y) largest = v.y;
+                    if (largest < v.z) largest = v.z;
+                    if (largest < v.w) largest = v.w;
+                }
 #pragma unroll
-            for (int q = 1; q < SIGMA / 4; ++q) {
-                const float4 v = col[q];
-                if (largest < v.x) largest = v.x;
-                if (largest < v.y) largest = v.y;
-                if (largest < v.z) largest = v.z;
-                if (largest < v.w) largest = v.w;
+                for (int q = 1; q < SIGMA / 4; ++q) {
+                    const float4 v = col[q];
+                    if (largest < v.x) largest = v.x;
+                    if (largest < v.y) largest = v.y;
+                    if (largest < v.z) largest = v.z;
+                    if (largest < v.w) largest = v.w;
+                }
+                cmw[mm][j] = largest;
             }
-            cmw[j] = largest;
         }
     };
     if (sites > 0) maxima(0, cmbuf[0], threadIdx.x, blockDim.x);
     uint32_t ci = 0;
     for (uint32_t c0 = 0; c0 < sites; c0 += CH, ++ci) {
         const uint32_t n = min((uint32_t)CH, sites - c0);
-        const float* cm = cmbuf[ci & 1];
         __syncthreads();                                   // this chunk's maxima are in place; the other buffer is free
         if (threadIdx.x >= 64) {
             if (c0 + CH < sites) maxima(c0 + CH, cmbuf[(ci + 1) & 1], threadIdx.x - 64, blockDim.x - 64);
         } else
-        if (threadIdx.x == 0) {
+        if (chain) {
             // The chain of float additions IS the algorithm (a scan would round differently).  A bare chain of dependent v_add_f32 costs
             // 4.0 ns per addition on this part (tools/micro_addchain.hip); until round 4 this loop took 9.5-10: the sums went back to LDS
             // and every trip waited for those writes (s_waitcnt lgkmcnt(0)) before its next reads.  Now the adding lane only READS LDS --
             // sixteen maxima per round trip, three register sets so that a set's reads are two sets (128 ns of additions) old when they
             // are needed -- and stores the sums straight to best[] (plain 4-byte stores: nothing ever waits for them).
+            const float* cm = cmbuf[ci & 1][threadIdx.x];
             float acc = carry;
             const float4* c4 = reinterpret_cast<const float4*>(cm);
             float* dst = b + c0 + 1;

@@ -95,6 +95,21 @@ def test_k13_lists_beyond_the_capped_capacity_fail_loudly(engine):
     check_against_oracle(engine, synth_matrices(2, 40, 4, 0.1, 77), [3, 3], 13, co.log_threshold(1.5, 4, 13))
 
 
+@pytest.mark.parametrize("sigma,k,sites", [(4, 8, 2500), (20, 3, 700)])
+def test_prefix_sums_of_several_matrices_per_workgroup(engine, sigma, k, sites):
+    """matrix::preprocess (window.cpp:16-27): the running sums of a call's matrices run M to a workgroup, one chain per lane (M by the matrix
+    count: 2 at cfg2); every M, with a matrix count that is no multiple of it and more sites than a chunk (2048 / M) holds."""
+    mats = synth_matrices(11, sites, sigma, 0.1, 4242 + sigma)
+    groups = np.array([1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6], dtype=np.uint32)
+    eps = co.log_threshold(1.5, sigma, k)
+    try:
+        for m in (1, 2, 4, 8):
+            engine.set_option("debug_prefix_mats", m)
+            check_against_oracle(engine, mats, groups, k, eps)
+    finally:
+        engine.set_option("debug_prefix_mats", 0)
+
+
 @pytest.mark.parametrize("k", list(range(2, 7)))
 def test_aa_all_k(engine, k):
     mats = synth_matrices(3, 20, 20, 0.03, 300 + k)
