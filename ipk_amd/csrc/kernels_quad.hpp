@@ -537,8 +537,22 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                 const float eps_l = thr[w * Q::TH_F], eps_r = thr[w * Q::TH_F + 1];
                 const uint32_t tl = nla * nlb, tr = nra * nrb;
                 uint32_t nL, nR;
-                wave_lds_sync();                                                 // the previous window's L / R are consumed
-                if (tl <= 64 && tr <= 64) {
+                // A half list beyond the wavefront's capacity (0.13 % of cfg2's windows) is taken in SLICES: as many rows of its first
+                // child as are sure to fit (CAP / 64 at least), every slice of L against every slice of R -- the same pairs in another
+                // order, through the same appender.  Until round 4 such windows were queued for a kernel of their own that put their
+                // pairs into the finished tables with global atomics (0.6 ms at cfg2, 0.14 ms of a rank's 2.9-ms share).
+                // Only with the row-per-lane join (k = 11, 12), whose count pass costs two instructions per column: the candidate-per-lane
+                // join of k <= 10 spends ~25 per step whenever one of a trip's 192 candidates passes, and a big window's |L| x |R| / 64
+                // steps through it came to 12.2 instead of 10.2 ms at cfg2 -- those windows keep their queue and their kernel.
+                constexpr bool SLICE = ROWLANE;
+                constexpr uint32_t SAFE_L = CAPL / Q::FLB, SAFE_R = CAPR / Q::FRB;
+                static_assert(SAFE_L >= 1 && SAFE_R >= 1, "a slice of one row of the first child must fit the list");
+                const bool one_step = tl <= 64 && tr <= 64;
+                uint32_t sla = nla, sra = nra, ia = 0, ir = 0;                   // rows of la / ra per slice, first row of the current slices
+                bool keep_l = false;                                             // L's current slice is built (R's slices pass by)
+                for (;;) {
+                wave_lds_sync();                                                 // the previous window's (slice's) L / R are consumed
+                if (one_step) {
                     // both half joins in one step
                     const float rnl = __builtin_amdgcn_rcpf((float)nlb), rnr = __builtin_amdgcn_rcpf((float)nrb);   // (1 ulp: ample for div_small)
                     const uint32_t il = div_small(lane_h, rnl), jl = (uint32_t)(__mul24((int)il, -(int)nlb) + (int)lane);
@@ -556,9 +570,15 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                 } else {
                     // (the list lengths are wave-uniform by construction; without the readfirstlane the branches below count as
                     //  divergent, and every value carried around this loop -- the appender's state -- is then held in VGPRs)
-                    nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)join_to_list(la, nla, lb, nlb, eps_l, Q::FLB * mulR, lp, CAPL));
-                    nR = nL == LIST_OVERFLOW || nL == 0 ? nL : (uint32_t)__builtin_amdgcn_readfirstlane((int)join_to_list(ra, nra, rb, nrb, eps_r, Q::FRB, rp, CAPR));
-                    if (nL == LIST_OVERFLOW || nR == LIST_OVERFLOW) {
+                    if (!keep_l)
+                        nL = (uint32_t)__builtin_amdgcn_readfirstlane((int)join_to_list(la + ia, min(sla, nla - ia), lb, nlb, eps_l, Q::FLB * mulR, lp, CAPL));
+                    if constexpr (SLICE) {
+                        if (nL == LIST_OVERFLOW) { sla = SAFE_L; continue; }            // (only a whole list overflows: ia == 0)
+                    }
+                    nR = nL == LIST_OVERFLOW || nL == 0 ? nL : (uint32_t)__builtin_amdgcn_readfirstlane((int)join_to_list(ra + ir, min(sra, nra - ir), rb, nrb, eps_r, Q::FRB, rp, CAPR));
+                    if constexpr (SLICE) {
+                        if (nR == LIST_OVERFLOW) { sra = SAFE_R; keep_l = true; continue; }   // (ir == 0; L's slice stays as it is)
+                    } else if (nL == LIST_OVERFLOW || nR == LIST_OVERFLOW) {
                         if (lane == 0) {
                             const uint32_t qi = atomicAdd(p.ovf_count, 1u);
                             p.ovf_queue[qi] = ((unsigned long long)mat << 32) | (unsigned long long)(t0 + w);
@@ -566,12 +586,13 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                         // (keeps the join of the one-lane branch out of the loop latch: a phi there that also merges other paths
                         //  would count as divergent, and with it every value carried around the loop -- see RowAppender::roll)
                         __builtin_amdgcn_wave_barrier();
-                        continue;
+                        break;
                     }
                 }
-                if (nL == 0 || nR == 0) continue;
+                if (nL != 0 && nR != 0) {
                 wave_lds_sync();
-                if (p.flags & 4u) { emitted += nL + nR; continue; }                 // diagnostics: list building only
+                if (p.flags & 4u) emitted += nL + nR;                               // diagnostics: list building only
+                else
                 if constexpr (ROWLANE) {
                     // ---- final join, one row of L per lane ---------------------------------------------------------------
                     constexpr uint32_t CB = 64;                                       // columns per round: a row's run is <= 64 <= CH pairs
@@ -753,6 +774,14 @@ __global__ __launch_bounds__(NW * 64) void score_quad_kernel(StreamParams p)
                     for (; i0 + 2 * rps <= nL; i0 += 2 * rps) trip(I2{}, std::true_type{}, i0);
                     if (i0 + rps < nL) trip(I2{}, std::false_type{}, i0);
                     else if (i0 < nL) trip(I1{}, std::false_type{}, i0);
+                }
+                }
+                // the next slices: R's behind the current L, then the next slice of L with R from its start
+                if (!SLICE || one_step) break;
+                ir += sra;
+                if (nL != 0 && ir < nra) { keep_l = true; continue; }
+                ir = 0; keep_l = false; ia += sla;
+                if (ia >= nla) break;
                 }
             }
         }

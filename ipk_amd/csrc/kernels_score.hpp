@@ -250,6 +250,9 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
 #define IPK_OVF_NW 8
 #endif
 constexpr int OVF_NW = IPK_OVF_NW;
+#ifndef IPK_OVF_NOPUT
+#define IPK_OVF_NOPUT 0            // 1: the big-list kernel without its table atomics (timing experiments; results wrong)
+#endif
 // Capacity of the big-list kernels' half lists.  Up to DNA k = 12 / AA k = 6 a window's worst-case lists (sigma^ceil(k/2) entries
 // each) fit LDS and nothing can overflow; from DNA k = 13 they do not (2 x 4^7 x 8 B = 256 KB), so the lists are capped at
 // BIG_CAP_ENTRIES and a window whose half list exceeds that raises *big_ovf: the call fails loudly (IPKGPU_ERR_INVALID) instead of
@@ -299,28 +302,39 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
         const uint32_t nL = sh_n[0], nR = sh_n[1];
         if (nL == 0 || nR == 0) continue;
         uint32_t cnt = 0;
-        // rows of L are dealt round-robin to the waves; lanes stride R
-        for (uint32_t i = wave; i < nL; i += OVF_NW) {
-            const uint2 a = L[i];
-            for (uint32_t jb = 0; jb < nR; jb += 64) {
-                const uint32_t j = jb + lane;
-                const bool valid = j < nR;
-                uint2 b = make_uint2(0, 0);
-                if (valid) b = R[j];
-                const float s = __uint_as_float(a.y) + __uint_as_float(b.y);      // pk_compute.cpp:90
-                const bool pass = valid && (s > p.eps);                            // :91
-                if (pass && !(p.flags & 1u)) {
-                    const uint32_t idx = a.x * mulR + b.x;
-                    if constexpr (POS) PutScorePos{tab64, inv_seq}(idx, __float_as_uint(s));
-                    else {
-                        // the returned old value says whether this is the slot's first score (measured cheaper than a plain
-                        // read of the mask word followed by a conditional atomicOr: 0.62 vs 0.74 ms at cfg2)
-                        const uint32_t old = atomicMax(tab + idx, enc_score_bits(__float_as_uint(s)));   // PutScore
-                        if (old == 0u && p.mask)
-                            atomicOr(p.mask + (size_t)p.mat_slot[mat] * p.mask_words + (idx >> 5), 1u << (idx & 31u));
+        // A block of 64 entries of R stays in registers while the rows of L (dealt round-robin to the waves) pass by, OVF_ROWS rows per
+        // trip with their LDS reads in flight together.  (Until round 4 every (row, block) step read both operands from LDS and waited
+        // for them: ~400 cycles per step, and the step count -- |L| x |R| / 64, 1 % of them pairs -- is what this kernel's time is:
+        // without its atomics it took as long.)
+        constexpr uint32_t OVF_ROWS = 4;
+        const bool no_put = (p.flags & 1u) != 0 || IPK_OVF_NOPUT;
+        for (uint32_t jb = 0; jb < nR; jb += 64) {
+            const uint32_t j = jb + lane;
+            const bool valid = j < nR;
+            uint2 b = make_uint2(0, 0);
+            if (valid) b = R[j];
+            const float by = __uint_as_float(b.y);
+            for (uint32_t i0 = wave; i0 < nL; i0 += OVF_NW * OVF_ROWS) {
+                uint2 a[OVF_ROWS];
+#pragma unroll
+                for (uint32_t u = 0; u < OVF_ROWS; ++u) a[u] = L[min(i0 + u * OVF_NW, nL - 1)];
+#pragma unroll
+                for (uint32_t u = 0; u < OVF_ROWS; ++u) {
+                    const float s = __uint_as_float(a[u].y) + by;                     // pk_compute.cpp:90
+                    const bool pass = valid && (i0 + u * OVF_NW < nL) && (s > p.eps);  // :91
+                    if (pass && !no_put) {
+                        const uint32_t idx = a[u].x * mulR + b.x;
+                        if constexpr (POS) PutScorePos{tab64, inv_seq}(idx, __float_as_uint(s));
+                        else {
+                            // the returned old value says whether this is the slot's first score (measured cheaper than a plain
+                            // read of the mask word followed by a conditional atomicOr: 0.62 vs 0.74 ms at cfg2)
+                            const uint32_t old = atomicMax(tab + idx, enc_score_bits(__float_as_uint(s)));   // PutScore
+                            if (old == 0u && p.mask)
+                                atomicOr(p.mask + (size_t)p.mat_slot[mat] * p.mask_words + (idx >> 5), 1u << (idx & 31u));
+                        }
                     }
+                    cnt += (uint32_t)__popcll(__ballot(pass));
                 }
-                cnt += (uint32_t)__popcll(__ballot(pass));
             }
         }
         emitted += cnt;
