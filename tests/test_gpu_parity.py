@@ -140,8 +140,9 @@ def test_rejects_bad_arguments(engine):
 
 
 def test_big_list_fallback_dna(engine):
-    # a permissive threshold makes the half lists exceed the fast path's capacity (4^5 > 256):
-    # those windows are re-done by the big-list kernel; results must not change
+    # a permissive threshold makes the half lists exceed the fast path's capacity (4^5 > 160, 4^6 > 384): at k = 10 those windows are
+    # re-done by the big-list kernel, at k = 12 the scoring kernel takes both lists in slices (here: every slice of L against every
+    # slice of R); results must not change
     mats = synth_matrices(2, 14, 4, 1.0, 9)
     check_against_oracle(engine, mats, [0, 0], 10, -9.0)
     mats = synth_matrices(1, 14, 4, 1.0, 10)
@@ -585,7 +586,7 @@ def test_row_per_lane_join_with_dense_rows(engine, k, alpha):
     """DNA k = 11, 12 (row-per-lane final join): flattish columns give rows with dozens of passing pairs each, so the eight
     rows of a key bucket reserve more than a chunk's worth in ONE round -- the bucket's chunk is closed early and crossed
     again in the new chunk (LaneAppender::roll_at, the re-examination loop) -- and, fully flat, lists beyond the fast
-    path's capacity (big-list windows through the pool, compressed tables)."""
+    path's capacity (taken in slices by the scoring kernel since round 4; compressed tables)."""
     mats = synth_matrices(4, 70, 4, alpha, 700 + k)
     check_against_oracle(engine, mats, [3, 3, 8, 8], k, co.log_threshold(1.5, 4, k))
     check_against_oracle(engine, mats, [3, 3, 8, 8], k, co.log_threshold(1.5, 4, k), device=True)
