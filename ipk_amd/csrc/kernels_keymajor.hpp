@@ -89,6 +89,17 @@ __global__ __launch_bounds__(256) void km_count_mask_kernel(const uint32_t* __re
 #pragma unroll
         for (int p = 0; p < 8; ++p) plane[p] = 0;
     }
+    if (P == 1 && w * 32 + 32 <= T) {
+        // one owner: the word's 32 counts are consecutive -- eight 16-byte stores per array instead of thirty-two 4-byte ones a line apart
+        uint4* c4 = reinterpret_cast<uint4*>(counts + w * 32);
+        uint4* q4 = reinterpret_cast<uint4*>(qpack + w * 32);
+#pragma unroll
+        for (int b = 0; b < 32; b += 4) {
+            c4[b >> 2] = make_uint4(total[b], total[b + 1], total[b + 2], total[b + 3]);
+            if (qpack) q4[b >> 2] = make_uint4(pack[b], pack[b + 1], pack[b + 2], pack[b + 3]);
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < 32; ++b) {
         const uint64_t x = w * 32 + b;
