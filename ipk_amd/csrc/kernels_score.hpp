@@ -1472,40 +1472,66 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_xp_kernel(XpParams
         __syncthreads();
         const uint32_t nL = sh_n[0], nR = sh_n[1];
         if (nL == 0 || nR == 0) continue;
-        for (uint32_t i = wave; i < nL; i += OVF_NW) {                         // rows of L dealt to the waves
-            const uint2 a = L[i];
-            const uint32_t bk = a.x / RPB;
-            const size_t slot = ((size_t)g * NB + bk) * xp.stride + (xp.stride - 1);
-            uint32_t c = 0;
+        // Rows of L in batches of XP_ROWS per wavefront: the batch's counts over one walk of R (a block of R in registers, the rows'
+        // values read once), then ONE global atomic instruction for the batch -- lane u reserves row u's run -- where every row used to
+        // wait for a returning atomic of its own (and for its offset's load), then the rows' stores.
+        constexpr uint32_t XP_ROWS = 8;
+        for (uint32_t i0 = wave * XP_ROWS; i0 < nL; i0 += OVF_NW * XP_ROWS) {
+            const uint32_t nrow = min(XP_ROWS, nL - i0);
+            uint2 a[XP_ROWS];
+            uint32_t c[XP_ROWS];
+#pragma unroll
+            for (uint32_t u = 0; u < XP_ROWS; ++u) { a[u] = L[min(i0 + u, nL - 1)]; c[u] = 0; }
             for (uint32_t jb = 0; jb < nR; jb += 64) {
                 const uint32_t j = jb + lane;
-                const float s = __uint_as_float(a.y) + __uint_as_float(j < nR ? R[j].y : 0u);   // pk_compute.cpp:90
-                c += (uint32_t)__popcll(__ballot(j < nR && s > p.eps));                           // :91
+                const bool valid = j < nR;
+                const float by = __uint_as_float(valid ? R[j].y : 0u);
+#pragma unroll
+                for (uint32_t u = 0; u < XP_ROWS; ++u) {
+                    const float s = __uint_as_float(a[u].y) + by;                                  // pk_compute.cpp:90
+                    c[u] += (uint32_t)__popcll(__ballot(valid && s > p.eps));                      // :91
+                }
             }
-            if (c == 0) continue;
+            // lane u holds row u's count and slot
+            uint32_t my_c = 0, my_ax = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < XP_ROWS; ++u)
+                if (lane == u) { my_c = u < nrow ? c[u] : 0u; my_ax = a[u].x; }
+            const uint32_t my_bk = my_ax / RPB;
+            const size_t my_slot = ((size_t)g * NB + my_bk) * xp.stride + (xp.stride - 1);
             if constexpr (!WRITE) {
-                if (lane == 0) atomicAdd(&xp.cnt[slot], c);
-                emitted += c;
+                if (my_c) atomicAdd(&xp.cnt[my_slot], my_c);
+                emitted += my_c;                                                                   // (per lane; summed at the end)
             } else {
-                uint32_t rel = 0;
-                if (lane == 0) rel = atomicAdd(&xp.ovcur[(size_t)g * NB + bk], c);
-                rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
-                uint2* dst = p.pool + xp.off[slot] + rel;
-                uint32_t done = 0;
-                for (uint32_t jb = 0; jb < nR; jb += 64) {
-                    const uint32_t j = jb + lane;
-                    uint2 b = make_uint2(0, 0);
-                    if (j < nR) b = R[j];
-                    const float s = __uint_as_float(a.y) + __uint_as_float(b.y);
-                    const bool pass = j < nR && s > p.eps;
-                    const uint64_t m = __ballot(pass);
-                    if (pass) dst[done + mbcnt(m)] = make_uint2(a.x * mulR + b.x, __float_as_uint(s));
-                    done += (uint32_t)__popcll(m);
+                unsigned long long my_dst = 0;
+                if (my_c) my_dst = reinterpret_cast<unsigned long long>(p.pool + xp.off[my_slot] + atomicAdd(&xp.ovcur[(size_t)g * NB + my_bk], my_c));
+#pragma unroll 1
+                for (uint32_t u = 0; u < nrow; ++u) {
+                    const uint32_t cu = (uint32_t)__builtin_amdgcn_readlane((int)my_c, (int)u);
+                    if (cu == 0) continue;
+                    const uint32_t dlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_dst, (int)u);
+                    const uint32_t dhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_dst >> 32), (int)u);
+                    uint2* dst = reinterpret_cast<uint2*>(((unsigned long long)dhi << 32) | dlo);
+                    const uint2 au = L[i0 + u];
+                    uint32_t done = 0;
+                    for (uint32_t jb = 0; jb < nR; jb += 64) {
+                        const uint32_t j = jb + lane;
+                        uint2 b = make_uint2(0, 0);
+                        if (j < nR) b = R[j];
+                        const float s = __uint_as_float(au.y) + __uint_as_float(b.y);
+                        const bool pass = j < nR && s > p.eps;
+                        const uint64_t m = __ballot(pass);
+                        if (pass) dst[done + mbcnt(m)] = make_uint2(au.x * mulR + b.x, __float_as_uint(s));
+                        done += (uint32_t)__popcll(m);
+                    }
                 }
             }
         }
     }
-    if (!WRITE && lane == 0 && emitted) atomicAdd(p.emitted, emitted);
+    if constexpr (!WRITE) {
+        for (int o = 32; o > 0; o >>= 1) emitted += __shfl_down(emitted, o, 64);                  // (per-lane counts: lanes 0..XP_ROWS-1)
+        if (lane == 0 && emitted) atomicAdd(p.emitted, emitted);
+    }
 }
 
 // xp pass 3: one workgroup per (group, bucket); its pairs are ONE contiguous range of the pool
