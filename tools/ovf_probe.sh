@@ -1,5 +1,17 @@
-for f in 0 1 0 1; do
-IPKGPU_DEBUG_FLAGS=$f python bench.py --e2e 0 --cpu-groups 0 --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/ovf_f$f.json
-python -c "
-import json; d=json.load(open('gpurun_out/ovf_f$f.json')); p=d['phases_ms_per_step']; print($f, round(d['ms_per_step'],3), round(p['score'],3), round(p['score_main_kernel'],3), round(p['score_lds_reduce'],3), 'other in score', round(p['score']-p['score_main_kernel']-p['score_lds_reduce'],3))"
-done
+#!/bin/bash
+# usage (on the GPU box): tools/mkvar.sh ovfnoput -DIPK_OVF_NOPUT=1 (here, beforehand); then tools/ovf_probe.sh
+# -- the big-list kernel of cfg2 (score_overflow_kernel) with and without its global atomics: rocprofv3 kernel stats of the in-tree
+#    library and of the IPK_OVF_NOPUT build (results of the latter are wrong: timing only)
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT
+unset IPKGPU_LIB
+bash tools/prof_stats.sh ovf_with
+export IPKGPU_LIB=$ROOT/ipk_amd/_variants/v_ovfnoput.so
+bash tools/prof_stats.sh ovf_without
+python3 - <<'PY'
+import csv
+for t in ("ovf_with", "ovf_without"):
+    for r in csv.DictReader(open("gpurun_out/%s_kernel_stats.csv" % t)):
+        if "score_overflow_kernel" in r["Name"]:
+            print(t, r["Name"][:60], r["Calls"], "calls", round(float(r["AverageNs"]) / 1e3, 1), "us")
+PY
