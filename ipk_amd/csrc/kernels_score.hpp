@@ -250,6 +250,9 @@ __global__ __launch_bounds__(NW * 64) void score_tiles_kernel(ScoreParams p)
 #define IPK_OVF_NW 8
 #endif
 constexpr int OVF_NW = IPK_OVF_NW;
+#ifndef IPK_OVF_UNCOND_OR
+#define IPK_OVF_UNCOND_OR 0        // 1: no-return atomicMax + an unconditional atomicOr on the occupancy bits (measured: see DESIGN A.4)
+#endif
 #ifndef IPK_OVF_NOPUT
 #define IPK_OVF_NOPUT 0            // 1: the big-list kernel without its table atomics (timing experiments; results wrong)
 #endif
@@ -328,9 +331,14 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
                         else {
                             // the returned old value says whether this is the slot's first score (measured cheaper than a plain
                             // read of the mask word followed by a conditional atomicOr: 0.62 vs 0.74 ms at cfg2)
+#if IPK_OVF_UNCOND_OR
+                            atomicMax(tab + idx, enc_score_bits(__float_as_uint(s)));                        // (no-return forms: nothing waits)
+                            if (p.mask) atomicOr(p.mask + (size_t)p.mat_slot[mat] * p.mask_words + (idx >> 5), 1u << (idx & 31u));
+#else
                             const uint32_t old = atomicMax(tab + idx, enc_score_bits(__float_as_uint(s)));   // PutScore
                             if (old == 0u && p.mask)
                                 atomicOr(p.mask + (size_t)p.mat_slot[mat] * p.mask_words + (idx >> 5), 1u << (idx & 31u));
+#endif
                         }
                     }
                     cnt += (uint32_t)__popcll(__ballot(pass));
