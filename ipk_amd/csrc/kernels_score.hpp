@@ -253,6 +253,9 @@ constexpr int OVF_NW = IPK_OVF_NW;
 #ifndef IPK_OVF_UNCOND_OR
 #define IPK_OVF_UNCOND_OR 0        // 1: no-return atomicMax + an unconditional atomicOr on the occupancy bits (measured: see DESIGN A.4)
 #endif
+#ifndef IPK_OVF_PEEK
+#define IPK_OVF_PEEK 0
+#endif
 #ifndef IPK_OVF_NOPUT
 #define IPK_OVF_NOPUT 0            // 1: the big-list kernel without its table atomics (timing experiments; results wrong)
 #endif
@@ -334,6 +337,14 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_kernel(ScoreParams
 #if IPK_OVF_UNCOND_OR
                             atomicMax(tab + idx, enc_score_bits(__float_as_uint(s)));                        // (no-return forms: nothing waits)
                             if (p.mask) atomicOr(p.mask + (size_t)p.mat_slot[mat] * p.mask_words + (idx >> 5), 1u << (idx & 31u));
+#elif IPK_OVF_PEEK
+                            // a plain look first: the slot's value only ever grows, so a score that does not beat what is there needs no atomic
+                            const uint32_t enc = enc_score_bits(__float_as_uint(s));
+                            if (__builtin_nontemporal_load(tab + idx) < enc) {
+                                const uint32_t old = atomicMax(tab + idx, enc);                              // PutScore
+                                if (old == 0u && p.mask)
+                                    atomicOr(p.mask + (size_t)p.mat_slot[mat] * p.mask_words + (idx >> 5), 1u << (idx & 31u));
+                            }
 #else
                             const uint32_t old = atomicMax(tab + idx, enc_score_bits(__float_as_uint(s)));   // PutScore
                             if (old == 0u && p.mask)
