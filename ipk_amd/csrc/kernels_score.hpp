@@ -1530,7 +1530,9 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_xp_kernel(XpParams
                     if (cu == 0) continue;
                     const uint32_t dlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_dst, (int)u);
                     const uint32_t dhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_dst >> 32), (int)u);
-                    uint2* dst = reinterpret_cast<uint2*>(((unsigned long long)dhi << 32) | dlo);
+                    // (a pointer rebuilt from lane values: told to be global memory, or the stores come out as flat_store -- tests/test_isa.py)
+                    typedef unsigned long long __attribute__((address_space(1)))* global_pair_ptr;
+                    const global_pair_ptr dst = (global_pair_ptr)(((unsigned long long)dhi << 32) | dlo);
                     const uint2 au = L[i0 + u];
                     uint32_t done = 0;
                     for (uint32_t jb = 0; jb < nR; jb += 64) {
@@ -1540,7 +1542,7 @@ __global__ __launch_bounds__(OVF_NW * 64) void score_overflow_xp_kernel(XpParams
                         const float s = __uint_as_float(au.y) + __uint_as_float(b.y);
                         const bool pass = j < nR && s > p.eps;
                         const uint64_t m = __ballot(pass);
-                        if (pass) dst[done + mbcnt(m)] = make_uint2(au.x * mulR + b.x, __float_as_uint(s));
+                        if (pass) dst[done + mbcnt(m)] = (unsigned long long)(au.x * mulR + b.x) | ((unsigned long long)__float_as_uint(s) << 32);
                         done += (uint32_t)__popcll(m);
                     }
                 }

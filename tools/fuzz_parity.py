@@ -1,0 +1,110 @@
+"""Randomised parity runs against the CPU oracle (a diagnostic tool: the oracle only checks, nothing here is product code).
+Every case: random alphabet, k, sites, matrices, grouping, column concentration, threshold, owners, batch size, prefix-kernel shape;
+the per-branch result (ipkgpu_score_groups) and the key-major database shards (ipkgpu_score_groups_keymajor + db_from_parts / merge)
+must equal the oracle's bit for bit.  Usage: python tools/fuzz_parity.py [seconds=240] [seed=1]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import ipk_amd
+from ipk_amd.synth import synth_matrices
+from oracle import ipk_oracle as co
+from oracle import db_oracle as dbo
+
+def run(budget=None, cases=None, seed=1, eng=None, max_k_dna=14, log=print):
+    """Runs until `budget` seconds have passed or `cases` cases are done; returns (cases, failures: list of descriptions)."""
+    rng = np.random.default_rng(seed)
+    own = eng is None
+    if own:
+        eng = ipk_amd.Engine(0)
+    t_end = time.time() + (budget if budget is not None else 1e9)
+    n_cases, fails = 0, []
+    try:
+        while time.time() < t_end and (cases is None or n_cases < cases):
+            _one(rng, eng, max_k_dna, fails, log)
+            n_cases += 1
+            if n_cases % 25 == 0:
+                log(f"{n_cases} cases, {len(fails)} failures")
+    finally:
+        eng.set_option("debug_prefix_mats", 0)
+        eng.set_option("workspace_bytes", 8 << 30)
+        if own:
+            eng.close()
+    return n_cases, fails
+
+
+def _one(rng, eng, max_k_dna, fails, log):
+    sigma = 4 if rng.random() < 0.7 else 20
+    k = int(rng.integers(2, max_k_dna + 1)) if sigma == 4 else int(rng.integers(2, 7))
+    alpha = float(np.exp(rng.uniform(np.log(0.03), np.log(1.0))))
+    flat = alpha > 0.4
+    if sigma == 4:
+        sites = int(rng.integers(k, 40 if (flat and k >= 10) else 300 if k <= 10 else 120))
+        if flat and k >= 12:
+            k = 11 if k > 12 else k
+            sites = int(rng.integers(k, k + 6))
+    else:
+        sites = int(rng.integers(k, 25 if (flat and k >= 5) else 120 if k <= 4 else 50))
+        if flat and k == 6:
+            alpha = 0.3
+    n_mats = int(rng.integers(1, 11))
+    n_groups = int(rng.integers(1, n_mats + 1))
+    ids = rng.choice(np.arange(1, 200), size=n_groups, replace=False).astype(np.uint32)
+    groups = np.sort(rng.integers(0, n_groups, size=n_mats))            # contiguous blocks ...
+    if rng.random() < 0.3:
+        groups = rng.permutation(groups)                                # ... or interleaved
+    mat_group = ids[groups]
+    omega = float(rng.choice([1.0, 1.25, 1.5, 2.0]))
+    eps = co.log_threshold(omega, sigma, k)
+    mats = synth_matrices(n_mats, sites, sigma, alpha, int(rng.integers(1, 1 << 30)))
+    if rng.random() < 0.1:
+        mats[rng.integers(0, n_mats), rng.integers(0, sites), rng.integers(0, sigma)] = -np.inf
+    owners = int(rng.choice([1, 1, 2, 3]))
+    pm = int(rng.choice([0, 0, 1, 2, 4, 8]))
+    small_ws = rng.random() < 0.2
+    desc = f"sigma={sigma} k={k} sites={sites} mats={n_mats} groups={mat_group.tolist()} alpha={alpha:.3f} omega={omega} owners={owners} prefix_mats={pm} small_ws={small_ws}"
+    try:
+        eng.set_option("debug_prefix_mats", pm)
+        eng.set_option("workspace_bytes", (1 << 22) if small_ws else (8 << 30))
+        order = list(dict.fromkeys(mat_group.tolist()))
+        ref, emitted = [], 0
+        for gid in order:
+            keys, scores, e = co.explore_group(mats[mat_group == gid], k, eps)
+            ref.append((gid, keys, scores)); emitted += e
+        res = eng.score_groups(mats, mat_group, k, eps)
+        assert res.group_ids.tolist() == order, "group order"
+        assert res.emitted == emitted, f"emitted {res.emitted} != {emitted}"
+        for gi, (gid, keys, scores) in enumerate(ref):
+            gk, gs = res.group(gi)
+            assert np.array_equal(gk, keys) and np.array_equal(gs.view(np.uint32), scores.view(np.uint32)), f"group {gid} differs"
+        res.free()
+        full = dbo.build_db(ref)
+        parts = eng.score_groups_keymajor(mats, mat_group, k, eps, n_owners=owners)
+        assert parts.emitted == emitted, "key-major emitted"
+        for o in range(owners):
+            if owners == 1:
+                db = eng.db_from_parts(parts, sigma, k)
+            else:
+                a, b = int(parts.owner_offsets[o]), int(parts.owner_offsets[o + 1])
+                db = eng.merge_parts(sigma, k, o, owners, parts.counts_tensor()[o:o + 1].contiguous(), parts.entries_tensor()[a:b].contiguous(), np.zeros(1, np.uint64))
+            keys, off, br, sc = dbo.db_shard_arrays(full, sigma, k, o, owners)
+            assert db.num_keys == len(keys) and db.num_entries == len(br), "shard sizes"
+            assert np.array_equal(db.keys(), keys) and np.array_equal(db.key_offsets(), off), "shard keys"
+            b_, s_ = db.entries()
+            assert np.array_equal(b_, br) and np.array_equal(s_.view(np.uint32), sc), "shard entries"
+            db.free()
+        parts.free()
+    except ipk_amd.IpkGpuError as ex:
+        if "half list exceeds" in str(ex) and k >= 13:
+            pass                                        # the documented cap of k = 13, 14
+        else:
+            fails.append(desc + " :: " + str(ex)); log("FAIL (error) " + desc + " " + str(ex))
+    except AssertionError as ex:
+        fails.append(desc + " :: " + str(ex)); log("FAIL " + desc + " " + str(ex))
+
+
+if __name__ == "__main__":
+    n, fails = run(budget=float(sys.argv[1]) if len(sys.argv) > 1 else 240.0, seed=int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                   log=lambda m: print(m, flush=True))
+    print(f"done: {n} cases, {len(fails)} failures", flush=True)
+    sys.exit(1 if fails else 0)
