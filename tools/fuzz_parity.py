@@ -94,6 +94,16 @@ def _one(rng, eng, max_k_dna, fails, log):
             assert np.array_equal(b_, br) and np.array_equal(s_.view(np.uint32), sc), "shard entries"
             db.free()
         parts.free()
+        if rng.random() < 0.3 and (sigma == 20 or k <= 10):
+            # the KEEP_POSITIONS flavour (ipk-aa-pos, branch_group.cpp:73-86): kept score + position of the first window reaching it
+            res = eng.score_groups_positions(mats, mat_group, k, eps)
+            assert res.group_ids.tolist() == order and res.emitted == emitted, "positions: order / emitted"
+            for gi, gid in enumerate(order):
+                keys, scores, pos, _ = co.explore_group_pos(mats[mat_group == gid], k, eps)
+                a, b = int(res.offsets[gi]), int(res.offsets[gi + 1])
+                assert np.array_equal(res.keys()[a:b], keys) and np.array_equal(res.scores()[a:b].view(np.uint32), scores.view(np.uint32)), f"positions: group {gid} differs"
+                assert np.array_equal(res.positions()[a:b], pos), f"positions of group {gid} differ"
+            res.free()
     except ipk_amd.IpkGpuError as ex:
         if "half list exceeds" in str(ex) and k >= 13:
             pass                                        # the documented cap of k = 13, 14
