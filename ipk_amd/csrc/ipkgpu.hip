@@ -232,12 +232,20 @@ static int fail(ipkgpu_ctx* ctx, int code, const char* fmt, ...)
     } while (0)
 #define RC_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
+// A workspace of at least `need` bytes.  One that has to GROW gets a sixteenth more than asked for: several sizes follow counts that vary a little
+// from call to call (chunks drawn, values per slice), and a buffer grown to the byte paid hipFree + hipMalloc of the whole block whenever the next
+// call needed one chunk more -- 1.2 s of a 0.1-s step for the 30-GB buffers of all of cfg3 on one GPU (tools/step_trace.py cfg3 1000).
 static int ensure(ipkgpu_ctx* ctx, DevBuf& b, size_t need)
 {
     if (b.cap >= need && b.p) return IPKGPU_OK;
+    const bool regrow = b.p != nullptr;
     if (b.p) { HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
-    HIP_TRY(ctx, hipMalloc(&b.p, std::max<size_t>(need, 16)));
-    b.cap = std::max<size_t>(need, 16);
+    need = std::max<size_t>(need, 16);
+    size_t want = regrow ? need + need / 16 : need;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess && want > need) { (void)hipGetLastError(); want = need; e = hipMalloc(&b.p, want); }   // (no room for the margin)
+    HIP_TRY(ctx, e);
+    b.cap = want;
     return IPKGPU_OK;
 }
 
